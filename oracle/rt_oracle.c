@@ -291,6 +291,21 @@ typedef struct {
     int from_outside;
 } hit_t;
 
+void orc_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+int orc_get_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
 void orc_material_default(orc_material *m) {
     memset(m, 0, sizeof *m);
     m->diffuse[0] = m->diffuse[1] = m->diffuse[2] = 1.0f;

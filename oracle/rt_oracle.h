@@ -56,6 +56,9 @@ enum { ORC_MODE_REF_1SPP = 0, ORC_MODE_REF_AA9 = 1, ORC_MODE_GRID = 2 };
 orc_scene *orc_scene_new(void);
 void orc_scene_free(orc_scene *s);
 void orc_material_default(orc_material *m);
+/* OpenMP threads used by the batch entry points (orc_trace_rays, orc_find_closest_hit, orc_render) */
+void orc_set_threads(int n);
+int orc_get_threads(void);
 
 /* glm restatements: column-major float[16] matrices. */
 void orc_mat_identity(float *m);

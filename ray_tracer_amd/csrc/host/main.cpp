@@ -1,0 +1,69 @@
+// main.cpp -- command-line driver.  Like the reference's `./main [out.ppm]` (main.cpp:1212-1288) it
+// builds a scene, renders it and writes an ASCII PPM; the scene, size and sampling are selectable:
+//   rt_main [out.ppm] [--preset shells|analytic|teapot|teapot_head|textured] [--size WxH]
+//           [--mode 1spp|aa9|gridN] [--depth D] [--assets DIR] [--brute] [--p6] [--device N]
+// Defaults reproduce the reference: preset shells, 1024x768, 1 spp, ./result.ppm.
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <stdexcept>
+
+#include "scene.hpp"
+
+using namespace rta;
+
+int main(int argc, const char *argv[]) {
+    std::string out = "./result.ppm", preset = "shells", assets = "assets";
+    int width = 1024, height = 768, mode = RT_MODE_REF_1SPP, grid = 1, depth = 8, device = 0, accel = RT_ACCEL_LBVH;
+    bool p6 = false;
+    for (int i = 1; i < argc; i++) {
+        std::string a = argv[i];
+        auto next = [&]() -> const char * { return i + 1 < argc ? argv[++i] : ""; };
+        if (a == "--preset") preset = next();
+        else if (a == "--assets") assets = next();
+        else if (a == "--size") { if (std::sscanf(next(), "%dx%d", &width, &height) != 2) { std::cerr << "bad --size\n"; return 2; } }
+        else if (a == "--mode") {
+            std::string m = next();
+            if (m == "1spp") mode = RT_MODE_REF_1SPP;
+            else if (m == "aa9") mode = RT_MODE_REF_AA9;
+            else if (m.rfind("grid", 0) == 0) { mode = RT_MODE_GRID; grid = std::atoi(m.c_str() + 4); }
+            else { std::cerr << "bad --mode\n"; return 2; }
+        } else if (a == "--depth") depth = std::atoi(next());
+        else if (a == "--device") device = std::atoi(next());
+        else if (a == "--brute") accel = RT_ACCEL_BRUTE;
+        else if (a == "--p6") p6 = true;
+        else if (a.rfind("--", 0) == 0) { std::cerr << "unknown option " << a << "\n"; return 2; }
+        else out = a;
+    }
+    try {
+        auto t0 = std::chrono::steady_clock::now();
+        std::cout << "Defining the scene..." << std::endl;
+        PresetHolder holder;
+        std::string err;
+        if (!build_preset(preset, assets, holder, err)) throw std::runtime_error(err);
+        Renderer renderer(device);
+        renderer.upload(holder.scene);
+        std::cout << "Coloring each pixel on the screen..." << std::endl;
+        rt_render_params p{};
+        p.width = width; p.height = height; p.fov = 90; p.mode = mode; p.grid_m = grid; p.max_depth = depth;
+        p.accel = accel; p.rank = 0; p.world_size = 1;
+        std::vector<uint8_t> rgb8(3 * (size_t)width * height);
+        renderer.render(p, nullptr, rgb8.data());
+        rt_counters c = renderer.counters();
+        double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        std::cout << "It took " << secs << " seconds to render the image." << std::endl;
+        std::cout << "I could render at " << 1.0 / secs << " frames per second." << std::endl;
+        unsigned long long rays = c.rays_primary + c.rays_shadow + c.rays_secondary;
+        std::cout << "trace kernel: " << c.last_trace_ms << " ms, " << rays << " rays, " << rays / (c.last_trace_ms * 1e3) << " Mrays/s; LBVH build "
+                  << c.last_build_ms << " ms" << std::endl;
+        Image image(width, height);
+        image.setPixels8(rgb8.data());
+        if (p6) image.writeImageBinary(out.c_str()); else image.writeImage(out.c_str());
+    } catch (const std::exception &e) {
+        std::cerr << "error: " << e.what() << std::endl;
+        return 1;
+    }
+    return 0;
+}

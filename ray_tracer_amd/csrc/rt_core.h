@@ -1,0 +1,804 @@
+// rt_core.h -- per-ray arithmetic of the renderer: intersection tests, LBVH traversal, Phong
+// shading and the iterative form of the reference's recursive trace_ray.
+//
+// Everything here is a pure inline function over plain device arrays, written once and used by
+// the HIP kernels in rt_device.hip.  The same header compiles as host C++ so that the logic can be
+// unit-tested on a machine without a GPU (tests/cpu_twin); that build is test scaffolding and is
+// never linked into the shipped library.
+//
+// Arithmetic follows the reference's evaluation order and float/double promotions (citations at
+// each function; paths are relative to the reference checkout).  Build with -ffp-contract=off:
+// comparisons must keep IEEE NaN semantics (a NaN refraction direction has to miss everything,
+// main.cpp:627-633) and hit/no-hit decisions should round like the reference's.
+#pragma once
+
+#include <math.h>
+#include <stdint.h>
+
+#include "rt_amd.h"
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define RT_HD __host__ __device__ __forceinline__
+#else
+#define RT_HD inline
+#endif
+
+namespace rtc {
+
+constexpr float kEps = 0.0001f;     // EPS, main.cpp:23
+constexpr float kMinDist = 0.01f;   // find_closest_hit threshold, main.cpp:705
+constexpr int kStackDepth = 40;     // LBVH traversal stack entries per ray
+constexpr double kPi = 3.14159265358979323846;
+
+struct v2 { float x, y; };
+struct v3 { float x, y, z; };
+struct alignas(16) f4 { float x, y, z, w; };
+
+RT_HD v3 V3(float x, float y, float z) { v3 r; r.x = x; r.y = y; r.z = z; return r; }
+RT_HD v3 ld3(const float *p) { return V3(p[0], p[1], p[2]); }
+RT_HD v3 operator+(v3 a, v3 b) { return V3(a.x + b.x, a.y + b.y, a.z + b.z); }
+RT_HD v3 operator-(v3 a, v3 b) { return V3(a.x - b.x, a.y - b.y, a.z - b.z); }
+RT_HD v3 operator*(v3 a, v3 b) { return V3(a.x * b.x, a.y * b.y, a.z * b.z); }
+RT_HD v3 operator*(v3 a, float s) { return V3(a.x * s, a.y * s, a.z * s); }
+RT_HD v3 operator/(v3 a, float s) { return V3(a.x / s, a.y / s, a.z / s); }
+RT_HD v3 operator-(v3 a) { return V3(-a.x, -a.y, -a.z); }
+// glm/detail/func_geometric.inl:48-55: (x + y) + z
+RT_HD float dot(v3 a, v3 b) { float tx = a.x * b.x, ty = a.y * b.y, tz = a.z * b.z; return tx + ty + tz; }
+// func_geometric.inl:70-78
+RT_HD v3 cross(v3 x, v3 y) { return V3(x.y * y.z - y.y * x.z, x.z * y.x - y.z * x.x, x.x * y.y - y.x * x.y); }
+RT_HD float length(v3 v) { return sqrtf(dot(v, v)); }
+// func_geometric.inl:84-89: v * (1 / sqrt(dot(v, v)))
+RT_HD v3 normalize(v3 v) { return v * (1.0f / sqrtf(dot(v, v))); }
+// func_geometric.inl:19-22
+RT_HD float distance(v3 p0, v3 p1) { return length(p1 - p0); }
+// func_geometric.inl:106-109
+RT_HD v3 reflect(v3 I, v3 N) { return I - (N * dot(N, I)) * 2.0f; }
+RT_HD bool has_nan(v3 a) { return !(a.x == a.x) || !(a.y == a.y) || !(a.z == a.z); }
+
+// mat4 * vec4 of glm/detail/type_mat4x4.inl:561-572 on a matrix stored as four 3-row columns:
+// (c0*x + c1*y) + (c2*z + c3*w)
+RT_HD v3 xform(const float *m, v3 p, float w) {
+    v3 add0 = ld3(m) * p.x + ld3(m + 3) * p.y;
+    v3 add1 = ld3(m + 6) * p.z + ld3(m + 9) * w;
+    return add0 + add1;
+}
+RT_HD v3 xform_point(const float *m, v3 p) { return xform(m, p, 1.0f); }
+RT_HD v3 xform_dir(const float *m, v3 p) { return xform(m, p, 0.0f); }
+// mat3(c0,c1,c2) * v, glm/detail/type_mat3x3.inl:468-474
+RT_HD v3 m3_mul(v3 c0, v3 c1, v3 c2, v3 v) {
+    return V3(c0.x * v.x + c1.x * v.y + c2.x * v.z, c0.y * v.x + c1.y * v.y + c2.y * v.z,
+              c0.z * v.x + c1.z * v.y + c2.z * v.z);
+}
+RT_HD float clamp01(float x) { float m = (x < 0.0f) ? 0.0f : x; return (1.0f < m) ? 1.0f : m; }
+
+// ---------------------------------------------------------------- device-side scene
+
+struct BvhNode {  // 64 bytes: both children's boxes, then the children
+    float lo0[3], hi0[3];
+    float lo1[3], hi1[3];
+    int32_t c0, c1;  // >= 0: internal node index (mesh-relative); < 0: ~c = sorted triangle position
+    int32_t pad0, pad1;
+};
+
+struct DevMesh {
+    float to_local[12], to_world[12], normal_mat[12], box_to_local[12];
+    float gate_lo[3], gate_hi[3];  // padded Box bounds for the conservative pre-test
+    int32_t tri_offset, tri_count, boxed, node_offset;
+    int32_t gate_tri_offset;  // first of this mesh's 12 gate triangles in DevScene::gate_tri
+    int32_t pad[3];
+};
+
+struct DevTexture {
+    int32_t kind;
+    uint32_t w, h;
+    uint32_t pad;
+    const uint8_t *maps[4];  // base colour, normal, occlusion, roughness
+};
+
+struct DevScene {
+    int32_t n_objects, n_lights;
+    const rt_object *objects;
+    const rt_sphere *spheres;
+    const rt_plane *planes;
+    const rt_cone *cones;
+    const DevMesh *meshes;
+    const f4 *tri_test;        // 3 x f4 per sorted triangle: p1 p2 p3 sn
+    const uint32_t *tri_key;   // per sorted triangle: 2*frag + (1 - sub), the tie-break order
+    const int32_t *tri_orig;   // sorted position -> index into the arrays below
+    const float *tri_nrm;      // [n][9]
+    const float *tri_uv;       // [n][6]
+    const int32_t *tri_material, *tri_frag, *tri_sub;
+    const f4 *gate_tri;        // 3 x f4 per Box triangle, 12 per mesh
+    const BvhNode *nodes;
+    const rt_material *materials;
+    const DevTexture *textures;
+    const float *light_pos, *light_color;
+    float ambient[3];
+};
+
+// per-thread work counters; the counting variant is a separate template instantiation
+struct Work {
+    uint32_t rays_primary, rays_shadow, rays_secondary;
+    uint32_t tri, box, gate, quadric, plane, shade, tex;
+};
+RT_HD void work_zero(Work &w) {
+    w.rays_primary = w.rays_shadow = w.rays_secondary = 0;
+    w.tri = w.box = w.gate = w.quadric = w.plane = w.shade = w.tex = 0;
+}
+
+// ---------------------------------------------------------------- textures
+
+// ImageTexture::getRGBAat, Textures.cpp:27-35.  `int % unsigned` is unsigned arithmetic.
+template <bool COUNT>
+RT_HD f4 tex_rgba(const DevTexture &t, int map, v2 uv, Work &wk) {
+    if (COUNT) wk.tex++;
+    float fx = 2 * uv.x * (float)t.w;
+    float fy = 2 * uv.y * (float)t.h;
+    int xi = (int)roundf(fx), yi = (int)roundf(fy);
+    uint32_t x = (uint32_t)xi % t.w;
+    uint32_t y = (uint32_t)yi % t.h;
+    uint32_t index = (y * t.w + x) * 4u;
+    const uint8_t *p = t.maps[map] + index;
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t px = *reinterpret_cast<const uint32_t *>(p);
+    f4 r;
+    r.x = (float)(px & 255u) / 255.f; r.y = (float)((px >> 8) & 255u) / 255.f;
+    r.z = (float)((px >> 16) & 255u) / 255.f; r.w = (float)(px >> 24) / 255.f;
+    return r;
+#else
+    f4 r;
+    r.x = (float)p[0] / 255.f; r.y = (float)p[1] / 255.f; r.z = (float)p[2] / 255.f; r.w = (float)p[3] / 255.f;
+    return r;
+#endif
+}
+// Texture::texture(uv): Textures.cpp:9-24 and 41-43
+template <bool COUNT>
+RT_HD v3 tex_color(const DevTexture &t, v2 uv, Work &wk) {
+    if (t.kind == RT_TEX_CHECKER) {
+        int v = (int)(floorf(16 * uv.x) + floorf(16 * uv.y)) % 2;
+        return V3((float)v, (float)v, (float)v);
+    }
+    if (t.kind == RT_TEX_RAINBOW) {
+        int v = (int)floorf(18 * (uv.x + uv.y)) % 3;
+        return v == 0 ? V3(1, 0, 0) : v == 1 ? V3(0, 1, 0) : v == 2 ? V3(0, 0, 1) : V3(0, 0, 0);
+    }
+    f4 c = tex_rgba<COUNT>(t, 0, uv, wk);
+    return V3(powf(c.x, 2.2f), powf(c.y, 2.2f), powf(c.z, 2.2f));
+}
+template <bool COUNT>
+RT_HD v3 tex_rgb(const DevTexture &t, int map, v2 uv, Work &wk) {
+    f4 c = tex_rgba<COUNT>(t, map, uv, wk);
+    return V3(c.x, c.y, c.z);
+}
+RT_HD const DevTexture *image_texture_of(const DevScene &S, const rt_material &m) {
+    if (m.texture < 0) return nullptr;
+    const DevTexture *t = &S.textures[m.texture];
+    return t->kind == RT_TEX_IMAGE ? t : nullptr;
+}
+
+// ---------------------------------------------------------------- analytic primitives
+
+struct Surf {  // a resolved hit (Hit, main.cpp:45-53)
+    v3 point, normal;
+    v2 uv;
+    int32_t material;
+    int32_t frag, sub;
+    bool from_outside;
+};
+
+// Plane::intersect, main.cpp:222-257.  Returns the ray parameter (the plane's `distance`).
+RT_HD bool plane_hit(const rt_plane &pl, v3 ro, v3 rd, float &t) {
+    v3 n = ld3(pl.normal);
+    float DdotN = dot(rd, n);
+    if (!(DdotN < 0)) return false;
+    float PdotN = dot(ld3(pl.point) - ro, n);
+    t = PdotN / DdotN;
+    return t > 0;
+}
+template <bool COUNT>
+RT_HD void plane_surface(const DevScene &S, const rt_plane &pl, v3 ro, v3 rd, float t, Surf &s, Work &wk) {
+    v3 n = ld3(pl.normal), b1 = ld3(pl.b1), b2 = ld3(pl.b2);
+    s.point = rd * t + ro;
+    s.uv.x = dot(b1, s.point);
+    s.uv.y = dot(b2, s.point);
+    s.material = pl.material;
+    const DevTexture *it = image_texture_of(S, S.materials[pl.material]);
+    if (it) {
+        v3 tn = tex_rgb<COUNT>(*it, 1, s.uv, wk);
+        tn = tn * 2.f - V3(1, 1, 1);
+        n = m3_mul(b1, b2, n, tn);
+    }
+    s.normal = normalize(n);
+    s.from_outside = true;
+    s.frag = 0;
+    s.sub = 0;
+}
+
+struct QuadricHit {
+    float t;  // local ray parameter of the chosen root
+    bool cap; // cone: the root lies above y = 1 and the cap plane is used
+    bool from_outside;
+    float distance;
+    v3 o, d, i; // local ray and local hit point
+};
+
+// Sphere::intersect, main.cpp:122-160 + 183 (geometry, acceptance inputs).  pow(x, 2) on floats is
+// double arithmetic in the reference.
+RT_HD bool sphere_geom(const rt_sphere &sp, v3 ro, v3 rd, QuadricHit &q) {
+    v3 o = xform_point(sp.to_local, ro);
+    v3 d = xform_dir(sp.to_local, rd);
+    float a = (float)((double)d.x * d.x + (double)d.y * d.y + (double)d.z * d.z);
+    float b = 2 * (d.x * o.x + d.y * o.y + d.z * o.z);
+    float c = (float)((double)o.x * o.x + (double)o.y * o.y + (double)o.z * o.z - 1);
+    float delta = (float)((double)b * b - (double)(4 * a * c));
+    if (delta < 0) return false;
+    float t1 = (-b + sqrtf(delta)) / (2 * a);
+    float t2 = (-b - sqrtf(delta)) / (2 * a);
+    if (t1 < 0 && t2 < 0) return false;
+    float ta = t1 < 0 ? INFINITY : t1, tb = t2 < 0 ? INFINITY : t2;
+    float t = tb < ta ? tb : ta;
+    q.t = t;
+    q.o = o; q.d = d;
+    q.i = o + d * t;
+    q.cap = false;
+    q.from_outside = !(fabsf(o.x) < 1 && fabsf(o.y) < 1 && fabsf(o.z) < 1);
+    q.distance = distance(ro, xform_point(sp.to_world, q.i));
+    return true;
+}
+// Sphere::intersect, main.cpp:153-181 (uv, normal mapping, world transform)
+template <bool COUNT>
+RT_HD void sphere_surface(const DevScene &S, const rt_sphere &sp, const QuadricHit &q, Surf &s, Work &wk) {
+    v3 i = q.i;
+    s.uv.x = (float)(((double)atan2f(i.z, i.x) + kPi) / kPi);
+    s.uv.y = (float)(((double)asinf(i.y) + kPi / 2) / kPi);
+    s.point = xform_point(sp.to_world, i);
+    s.material = sp.material;
+    const DevTexture *it = image_texture_of(S, S.materials[sp.material]);
+    v3 n;
+    if (it) {
+        v3 tangent = V3(sinf(s.uv.x), 0, cosf(s.uv.x));
+        v3 bitangent = cross(i, tangent);
+        v3 tn = tex_rgb<COUNT>(*it, 1, s.uv, wk);
+        tn = tn * 2.f - V3(1, 1, 1);
+        tn = m3_mul(normalize(tangent), normalize(bitangent), normalize(i), tn);
+        n = xform_dir(sp.normal_mat, tn);
+    } else {
+        n = xform_dir(sp.normal_mat, i);
+    }
+    s.normal = normalize(n);
+    s.from_outside = q.from_outside;
+    s.frag = 0;
+    s.sub = 0;
+}
+
+// Cone::intersect, main.cpp:269-325
+RT_HD bool cone_geom(const rt_cone &cn, v3 ro, v3 rd, QuadricHit &q) {
+    v3 d = xform_dir(cn.to_local, rd);
+    v3 o = xform_point(cn.to_local, ro);
+    float a = (float)((double)d.x * d.x - (double)d.y * d.y + (double)d.z * d.z);
+    float b = 2 * (d.x * o.x - d.y * o.y + d.z * o.z);
+    float c = (float)((double)o.x * o.x - (double)o.y * o.y + (double)o.z * o.z);
+    float delta = (float)((double)b * b - (double)(4 * a * c));
+    if (delta < 0) return false;
+    float t1 = (-b + sqrtf(delta)) / (2 * a);
+    float t2 = (-b - sqrtf(delta)) / (2 * a);
+    if (t1 < 0 && t2 < 0) return false;
+    v3 i1 = o + d * t1, i2 = o + d * t2;
+    if ((i1.y < 0 && i2.y < 0) || (i1.y > 1 && i2.y > 1)) return false;
+    float ta = t1 < 0 ? INFINITY : t1, tb = t2 < 0 ? INFINITY : t2;
+    float t = tb < ta ? tb : ta;
+    v3 i = o + d * t;
+    q.o = o; q.d = d;
+    q.cap = i.y > 1;
+    q.from_outside = true;
+    if (q.cap) {
+        float tp;
+        if (!plane_hit(cn.cap, o, d, tp)) return false;  // the cap is tested with the local ray
+        q.t = tp;
+        q.i = d * tp + o;
+    } else {
+        q.t = t;
+        q.i = i;
+    }
+    q.distance = distance(ro, xform_point(cn.to_world, q.i));
+    return true;
+}
+template <bool COUNT>
+RT_HD void cone_surface(const DevScene &S, const rt_cone &cn, const QuadricHit &q, Surf &s, Work &wk) {
+    v3 n;
+    if (q.cap) {
+        Surf ps;
+        plane_surface<COUNT>(S, cn.cap, q.o, q.d, q.t, ps, wk);
+        s.uv = ps.uv;
+        n = ps.normal;
+        s.point = ps.point;
+    } else {
+        v3 i = q.i;
+        float y = (float)(((double)i.x * i.x + (double)i.z * i.z) / i.y + i.y);
+        n = i - V3(0, y, 0);
+        s.uv.x = atan2f(i.x, i.z);
+        s.uv.y = i.y;
+        s.point = i;
+    }
+    s.point = xform_point(cn.to_world, s.point);
+    s.normal = normalize(xform_dir(cn.normal_mat, n));
+    s.material = cn.material;
+    s.from_outside = true;
+    s.frag = 0;
+    s.sub = q.cap ? 1 : 0;
+}
+
+// ---------------------------------------------------------------- triangles and meshes
+
+struct TriBest {
+    float t;
+    int32_t k;     // sorted triangle position, -1: none
+    uint32_t key;  // tie-break order of k
+};
+
+// Triangle::intersect, main.cpp:372-395 (hit / no-hit and the ray parameter).  The candidate
+// replaces the current best when its t is smaller, or equal with a smaller key: Mesh::intersect
+// keeps the first fragment among equal t (main.cpp:536) and Diamond::intersect the second
+// triangle of a quad (main.cpp:476); keys encode exactly that order, so the result does not
+// depend on the order in which triangles are visited.
+template <bool COUNT>
+RT_HD void tri_test(const f4 *tt, int32_t k, uint32_t key, v3 o, v3 d, TriBest &best, Work &wk) {
+    if (COUNT) wk.tri++;
+    f4 A = tt[3 * k], B = tt[3 * k + 1], C = tt[3 * k + 2];
+    v3 p1 = V3(A.x, A.y, A.z), p2 = V3(A.w, B.x, B.y), p3 = V3(B.z, B.w, C.x), sn = V3(C.y, C.z, C.w);
+    float DdotN = dot(d, sn);
+    if (!(DdotN < 0)) return;
+    float PdotN = dot(p1 - o, sn);
+    float t = PdotN / DdotN;
+    if (!(t > 0)) return;
+    if (t > best.t || (t == best.t && key > best.key)) return;
+    v3 p = d * t + o;
+    v3 sn1 = cross(p2 - p, p3 - p);
+    v3 sn2 = cross(p3 - p, p1 - p);
+    v3 sn3 = cross(p1 - p, p2 - p);
+    // glm::sign(x) < 0 is x < 0; zero and NaN pass (main.cpp:390-395)
+    if (dot(sn1, sn) < 0 || dot(sn2, sn) < 0 || dot(sn3, sn) < 0) return;
+    best.t = t;
+    best.k = k;
+    best.key = key;
+}
+
+// hit / no-hit only (the Box gate, main.cpp:609-615)
+RT_HD bool tri_hits(const f4 *tt, int32_t k, v3 o, v3 d) {
+    TriBest b;
+    b.t = INFINITY; b.k = -1; b.key = 0xffffffffu;
+    Work wk;
+    tri_test<false>(tt, k, 0u, o, d, b, wk);
+    return b.k >= 0;
+}
+
+// Triangle::intersect, main.cpp:397-413: interpolated normal, uv, from_outside (local space)
+RT_HD void tri_surface(const DevScene &S, int32_t k, float t, v3 o, v3 d, v3 &p, v3 &n, v2 &uv,
+                       bool &from_outside, int32_t &orig) {
+    const f4 *tt = S.tri_test;
+    f4 A = tt[3 * k], B = tt[3 * k + 1], C = tt[3 * k + 2];
+    v3 p1 = V3(A.x, A.y, A.z), p2 = V3(A.w, B.x, B.y), p3 = V3(B.z, B.w, C.x), sn = V3(C.y, C.z, C.w);
+    p = d * t + o;
+    v3 sn1 = cross(p2 - p, p3 - p);
+    v3 sn2 = cross(p3 - p, p1 - p);
+    v3 sn3 = cross(p1 - p, p2 - p);
+    orig = S.tri_orig[k];
+    const float *nr = S.tri_nrm + 9 * (size_t)orig;
+    float l1 = length(sn1), l2 = length(sn2), l3 = length(sn3);
+    n = normalize((ld3(nr) * l1 + ld3(nr + 3) * l2) + ld3(nr + 6) * l3);
+    float W = length(sn);
+    const float *tu = S.tri_uv + 6 * (size_t)orig;
+    v3 u1 = V3(tu[0], tu[1], 0), u2 = V3(tu[2], tu[3], 0), u3 = V3(tu[4], tu[5], 0);
+    if (sqrtf(u1.x * u1.x + u1.y * u1.y) > 0) {
+        float w1 = length(sn1 / W), w2 = length(sn2 / W), w3 = length(sn3 / W);
+        v3 r = (u1 * w1 + u2 * w2) + u3 * w3;
+        uv.x = r.x; uv.y = r.y;
+    } else {
+        uv.x = l1 / W; uv.y = l2 / W;
+    }
+    from_outside = dot(n, d) < 0;
+}
+
+// Ray/box slab test against bounds that were padded at build time.  NaN products (0 * inf) are
+// dropped by fminf/fmaxf, which makes the test conservative for rays lying in a bounding plane.
+RT_HD bool slab(const float *lo, const float *hi, v3 o, v3 inv, float tmax, float &tnear) {
+    float ax = (lo[0] - o.x) * inv.x, bx = (hi[0] - o.x) * inv.x;
+    float ay = (lo[1] - o.y) * inv.y, by = (hi[1] - o.y) * inv.y;
+    float az = (lo[2] - o.z) * inv.z, bz = (hi[2] - o.z) * inv.z;
+    float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
+    float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tmax));
+    tnear = tn;
+    return tn <= tf * 1.0000004f;
+}
+
+// Closest triangle of a mesh for a local-space ray: stack traversal of the mesh's LBVH.
+// Stack is any type with push(int) / pop() / empty().
+template <bool COUNT, class Stack>
+RT_HD void bvh_closest(const DevScene &S, const DevMesh &m, v3 o, v3 d, TriBest &best, Stack &stk, Work &wk) {
+    const BvhNode *nodes = S.nodes + m.node_offset;
+    const f4 *tt = S.tri_test + 3 * (size_t)m.tri_offset;
+    const uint32_t *keys = S.tri_key + m.tri_offset;
+    v3 inv = V3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    stk.reset();
+    int32_t cur = 0;
+    if (m.tri_count == 1) cur = ~0;
+    for (;;) {
+        if (cur < 0) {
+            int32_t k = ~cur;
+            tri_test<COUNT>(tt, k, keys[k], o, d, best, wk);
+            if (stk.empty()) break;
+            cur = stk.pop();
+            continue;
+        }
+        const BvhNode &nd = nodes[cur];
+        if (COUNT) wk.box += 2;
+        float n0, n1;
+        bool h0 = slab(nd.lo0, nd.hi0, o, inv, best.t, n0);
+        bool h1 = slab(nd.lo1, nd.hi1, o, inv, best.t, n1);
+        if (h0 && h1) {
+            int32_t nearc = nd.c0, farc = nd.c1;
+            if (n1 < n0) { nearc = nd.c1; farc = nd.c0; }
+            stk.push(farc);
+            cur = nearc;
+        } else if (h0) {
+            cur = nd.c0;
+        } else if (h1) {
+            cur = nd.c1;
+        } else {
+            if (stk.empty()) break;
+            cur = stk.pop();
+        }
+    }
+}
+
+// Mesh::intersect (main.cpp:525-547) behind the optional Box gate (main.cpp:599-618): geometry and
+// the acceptance inputs of find_closest_hit.
+struct MeshHit {
+    float t;        // local ray parameter (Triangle's `distance`)
+    int32_t k;      // sorted triangle position
+    float distance; // Euclidean, world space (main.cpp:545)
+    bool from_outside;
+    v3 o, d;        // local ray
+};
+
+template <bool COUNT, class Stack>
+RT_HD bool mesh_geom(const DevScene &S, const DevMesh &m, v3 ro, v3 rd, int accel, MeshHit &mh, Stack &stk, Work &wk) {
+    if (m.tri_count <= 0) return false;
+    if (has_nan(ro) || has_nan(rd)) return false;  // every triangle test fails on NaN inputs
+    if (m.boxed) {
+        v3 bd = xform_dir(m.box_to_local, rd);
+        v3 bo = xform_point(m.box_to_local, ro);
+        v3 binv = V3(1.0f / bd.x, 1.0f / bd.y, 1.0f / bd.z);
+        float tn;
+        if (COUNT) wk.box++;
+        if (!slab(m.gate_lo, m.gate_hi, bo, binv, INFINITY, tn)) return false;
+        if (COUNT) wk.gate++;
+        const f4 *gt = S.gate_tri + 3 * (size_t)m.gate_tri_offset;
+        bool any = false;
+        for (int i = 0; i < 12; i++) any = any || tri_hits(gt, i, bo, bd);
+        if (!any) return false;
+    }
+    v3 d = xform_dir(m.to_local, rd);
+    v3 o = xform_point(m.to_local, ro);
+    TriBest best;
+    best.t = INFINITY; best.k = -1; best.key = 0xffffffffu;
+    if (accel == RT_ACCEL_BRUTE) {
+        const f4 *tt = S.tri_test + 3 * (size_t)m.tri_offset;
+        const uint32_t *keys = S.tri_key + m.tri_offset;
+        for (int32_t k = 0; k < m.tri_count; k++) tri_test<COUNT>(tt, k, keys[k], o, d, best, wk);
+    } else {
+        bvh_closest<COUNT>(S, m, o, d, best, stk, wk);
+    }
+    if (best.k < 0) return false;
+    mh.t = best.t;
+    mh.k = best.k + m.tri_offset;
+    mh.o = o; mh.d = d;
+    v3 p, n; v2 uv; int32_t orig;
+    tri_surface(S, mh.k, mh.t, o, d, p, n, uv, mh.from_outside, orig);
+    mh.distance = distance(ro, xform_point(m.to_world, p));
+    return true;
+}
+RT_HD void mesh_surface(const DevScene &S, const DevMesh &m, const MeshHit &mh, Surf &s) {
+    v3 p, n; int32_t orig;
+    tri_surface(S, mh.k, mh.t, mh.o, mh.d, p, n, s.uv, s.from_outside, orig);
+    s.point = xform_point(m.to_world, p);
+    s.normal = normalize(xform_dir(m.normal_mat, n));
+    s.material = S.tri_material[orig];
+    s.frag = S.tri_frag[orig];
+    s.sub = S.tri_sub[orig];
+}
+
+// ---------------------------------------------------------------- closest hit
+
+struct Closest {
+    float distance;
+    int32_t object;  // -1: miss
+    // what is needed to resolve the winner without repeating the search
+    float t;
+    int32_t k;
+    bool cap, from_outside;
+    v3 o, d, i;
+};
+
+// find_closest_hit, main.cpp:697-709: objects in list order, strict `<` keeps the first of equals
+template <bool COUNT, class Stack>
+RT_HD void find_closest(const DevScene &S, v3 ro, v3 rd, int accel, Closest &best, Stack &stk, Work &wk) {
+    best.distance = INFINITY;
+    best.object = -1;
+    for (int32_t k = 0; k < S.n_objects; k++) {
+        rt_object ob = S.objects[k];
+        if (ob.kind == RT_OBJ_PLANE) {
+            float t;
+            if (COUNT) wk.plane++;
+            if (plane_hit(S.planes[ob.index], ro, rd, t) && t > kMinDist && t < best.distance) {
+                best.distance = t; best.object = k; best.t = t; best.from_outside = true;
+            }
+        } else if (ob.kind == RT_OBJ_MESH) {
+            MeshHit mh;
+            if (mesh_geom<COUNT>(S, S.meshes[ob.index], ro, rd, accel, mh, stk, wk) && mh.from_outside &&
+                mh.distance > kMinDist && mh.distance < best.distance) {
+                best.distance = mh.distance; best.object = k; best.t = mh.t; best.k = mh.k;
+                best.o = mh.o; best.d = mh.d; best.from_outside = true;
+            }
+        } else {
+            QuadricHit q;
+            if (COUNT) wk.quadric++;
+            bool hit = ob.kind == RT_OBJ_SPHERE ? sphere_geom(S.spheres[ob.index], ro, rd, q)
+                                                : cone_geom(S.cones[ob.index], ro, rd, q);
+            if (hit && q.from_outside && q.distance > kMinDist && q.distance < best.distance) {
+                best.distance = q.distance; best.object = k; best.t = q.t; best.cap = q.cap;
+                best.o = q.o; best.d = q.d; best.i = q.i; best.from_outside = q.from_outside;
+            }
+        }
+    }
+}
+
+template <bool COUNT>
+RT_HD void resolve(const DevScene &S, const Closest &c, v3 ro, v3 rd, Surf &s, Work &wk) {
+    rt_object ob = S.objects[c.object];
+    if (ob.kind == RT_OBJ_PLANE) {
+        plane_surface<COUNT>(S, S.planes[ob.index], ro, rd, c.t, s, wk);
+    } else if (ob.kind == RT_OBJ_MESH) {
+        MeshHit mh;
+        mh.t = c.t; mh.k = c.k; mh.o = c.o; mh.d = c.d;
+        mesh_surface(S, S.meshes[ob.index], mh, s);
+    } else {
+        QuadricHit q;
+        q.t = c.t; q.cap = c.cap; q.o = c.o; q.d = c.d; q.i = c.i; q.from_outside = c.from_outside;
+        if (ob.kind == RT_OBJ_SPHERE) sphere_surface<COUNT>(S, S.spheres[ob.index], q, s, wk);
+        else cone_surface<COUNT>(S, S.cones[ob.index], q, s, wk);
+    }
+}
+
+// Object::intersect for one object without the closest-hit filters (the per-object parity entry)
+template <bool COUNT, class Stack>
+RT_HD void intersect_object(const DevScene &S, int32_t k, v3 ro, v3 rd, int accel, rt_hit_record &out, Stack &stk, Work &wk) {
+    Closest c;
+    c.object = -1; c.distance = INFINITY; c.from_outside = true;
+    rt_object ob = S.objects[k];
+    bool hit = false;
+    if (ob.kind == RT_OBJ_PLANE) {
+        float t;
+        hit = plane_hit(S.planes[ob.index], ro, rd, t);
+        c.t = t; c.distance = t;
+    } else if (ob.kind == RT_OBJ_MESH) {
+        MeshHit mh;
+        hit = mesh_geom<COUNT>(S, S.meshes[ob.index], ro, rd, accel, mh, stk, wk);
+        if (hit) { c.t = mh.t; c.k = mh.k; c.o = mh.o; c.d = mh.d; c.distance = mh.distance; c.from_outside = mh.from_outside; }
+    } else {
+        QuadricHit q;
+        hit = ob.kind == RT_OBJ_SPHERE ? sphere_geom(S.spheres[ob.index], ro, rd, q) : cone_geom(S.cones[ob.index], ro, rd, q);
+        if (hit) { c.t = q.t; c.cap = q.cap; c.o = q.o; c.d = q.d; c.i = q.i; c.distance = q.distance; c.from_outside = q.from_outside; }
+    }
+    out.hit = hit ? 1 : 0;
+    out.object = hit ? k : -1;
+    out.frag = 0; out.sub = 0;
+    out.from_outside = c.from_outside ? 1 : 0;
+    out.distance = hit ? c.distance : INFINITY;
+    for (int i = 0; i < 3; i++) { out.normal[i] = 0; out.point[i] = 0; }
+    out.uv[0] = out.uv[1] = 0;
+    if (hit) {
+        c.object = k;
+        Surf s;
+        resolve<COUNT>(S, c, ro, rd, s, wk);
+        out.frag = s.frag; out.sub = s.sub;
+        out.normal[0] = s.normal.x; out.normal[1] = s.normal.y; out.normal[2] = s.normal.z;
+        out.point[0] = s.point.x; out.point[1] = s.point.y; out.point[2] = s.point.z;
+        out.uv[0] = s.uv.x; out.uv[1] = s.uv.y;
+    }
+}
+
+// ---------------------------------------------------------------- shading
+
+// refract, main.cpp:627-633 (not glm::refract; no total-internal-reflection branch)
+RT_HD v3 refract_dir(v3 i, v3 n, float index) {
+    v3 a = n * dot(i, n);
+    v3 b = i - a;
+    float beta = 1 / index;
+    float alpha = (float)sqrt(1 + (1 - (double)beta * beta) * (double)(dot(b, b) / dot(a, a)));
+    return a * alpha + b * beta;
+}
+
+// PhongModel, main.cpp:642-695.  The texture lookups do not depend on the light and are hoisted.
+template <bool COUNT, class Stack>
+RT_HD v3 phong(const DevScene &S, const Surf &s, v3 view, int accel, Stack &stk, Work &wk) {
+    const rt_material &m = S.materials[s.material];
+    v3 color = ld3(S.ambient) * ld3(m.ambient);
+    const DevTexture *tex = m.texture >= 0 ? &S.textures[m.texture] : nullptr;
+    const DevTexture *img = (tex && tex->kind == RT_TEX_IMAGE) ? tex : nullptr;
+    v3 dc = ld3(m.diffuse);
+    if (tex) dc = tex_color<COUNT>(*tex, s.uv, wk);
+    float shininess = m.shininess;
+    if (img) shininess = (float)(.5 / pow((double)tex_rgba<COUNT>(*img, 3, s.uv, wk).x, 4.0) - .5);
+    v3 spec_col = ld3(m.specular);
+    for (int l = 0; l < S.n_lights; l++) {
+        v3 lp = ld3(S.light_pos + 3 * l);
+        v3 L = normalize(lp - s.point);
+        wk.rays_shadow++;
+        Closest sh;
+        find_closest<COUNT>(S, s.point + L * kEps, L, accel, sh, stk, wk);
+        if (sh.distance < distance(s.point, lp)) continue;
+        if (COUNT) wk.shade++;
+        v3 R = reflect(-L, s.normal);
+        float NdotL = clamp01(dot(s.normal, L));
+        float VdotR = clamp01(dot(view, R));
+        v3 diffuse = dc * V3(NdotL, NdotL, NdotL);
+        if (img) diffuse = diffuse * 5.f;
+        float sp = powf(VdotR, shininess);
+        v3 specular = spec_col * V3(sp, sp, sp);
+        float r = distance(s.point, lp);
+        r = (r < 0.1f) ? 0.1f : r;
+        v3 term = ld3(S.light_color + 3 * l) * (diffuse + specular);
+        term = term * 1.3f;
+        term = term / r;
+        term = term / r;
+        color = color + term;
+    }
+    if (img) color = color * tex_rgb<COUNT>(*img, 2, s.uv, wk);
+    else color = color * 4.0f;
+    color = color * 2.0f;
+    return color;
+}
+
+// trace_ray, main.cpp:716-761, as a loop.  The reference's result is linear in the radiance of
+// the child rays, so each pending ray carries the product of the blend factors on its path:
+//   local shading      weight * (1 - refl) * (ratio if refractive else 1)
+//   refraction child   weight * (1 - refl) * (1 - ratio)
+//   reflection child   weight * refl
+// Rays deeper than max_depth are dropped (the reference recurses without bound).
+struct Pending { v3 o, d; float w; int32_t depth; };
+
+template <bool COUNT, class Stack>
+RT_HD v3 trace(const DevScene &S, v3 ro, v3 rd, int max_depth, int accel, Stack &stk, Work &wk,
+               rt_hit_record *first_hit) {
+    Pending pend[RT_MAX_DEPTH + 1];
+    int np = 0;
+    v3 radiance = V3(0, 0, 0);
+    v3 o = ro, d = rd;
+    float weight = 1.0f;
+    int depth = 0;
+    bool primary = true;
+    for (;;) {
+        if (primary) wk.rays_primary++; else wk.rays_secondary++;
+        Closest c;
+        find_closest<COUNT>(S, o, d, accel, c, stk, wk);
+        Surf s;
+        if (c.object >= 0) resolve<COUNT>(S, c, o, d, s, wk);
+        if (primary && first_hit) {
+            rt_hit_record &h = *first_hit;
+            h.hit = c.object >= 0; h.object = c.object; h.from_outside = 1; h.distance = c.distance;
+            h.frag = 0; h.sub = 0;
+            for (int i = 0; i < 3; i++) { h.normal[i] = 0; h.point[i] = 0; }
+            h.uv[0] = h.uv[1] = 0;
+            if (c.object >= 0) {
+                h.frag = s.frag; h.sub = s.sub;
+                h.normal[0] = s.normal.x; h.normal[1] = s.normal.y; h.normal[2] = s.normal.z;
+                h.point[0] = s.point.x; h.point[1] = s.point.y; h.point[2] = s.point.z;
+                h.uv[0] = s.uv.x; h.uv[1] = s.uv.y;
+            }
+        }
+        primary = false;
+        bool have_next = false;
+        if (c.object >= 0) {
+            const rt_material &m = S.materials[s.material];
+            v3 local = phong<COUNT>(S, s, normalize(-d), accel, stk, wk);
+            float refl = m.reflectiveness, refr = m.refractiveness, ratio = m.refractive_ratio;
+            float w_after_refl = refl > 0 ? weight * (1 - refl) : weight;
+            float w_local = refr > 0 ? w_after_refl * ratio : w_after_refl;
+            radiance = radiance + local * w_local;
+            int cd = depth + 1;
+            bool deeper = cd <= max_depth;
+            v3 no = o, ndv = d;
+            float nw = 0;
+            if (refr > 0 && deeper) {
+                float index = s.from_outside ? refr : 1 / refr;
+                v3 rdir = refract_dir(d, s.normal, index);
+                no = s.point + rdir * kEps; ndv = rdir; nw = w_after_refl * (1.f - ratio);
+                have_next = true;
+            }
+            if (refl > 0 && s.from_outside && deeper) {
+                v3 rdir = reflect(d, s.normal);
+                v3 ro2 = s.point + rdir * kEps;
+                float rw = weight * refl;
+                if (have_next) {
+                    if (np <= RT_MAX_DEPTH) { pend[np].o = ro2; pend[np].d = rdir; pend[np].w = rw; pend[np].depth = cd; np++; }
+                } else {
+                    no = ro2; ndv = rdir; nw = rw; have_next = true;
+                }
+            }
+            if (have_next) { o = no; d = ndv; weight = nw; depth = cd; }
+        }
+        if (!have_next) {
+            if (np == 0) break;
+            np--;
+            o = pend[np].o; d = pend[np].d; weight = pend[np].w; depth = pend[np].depth;
+        }
+    }
+    return radiance;
+}
+
+// ---------------------------------------------------------------- camera, tone mapping
+
+struct Camera { float s, X, Y; };
+// main.cpp:1231-1233
+RT_HD Camera make_camera(int w, int h, float fov) {
+    Camera c;
+    c.s = (float)(2 * tan(0.5 * (double)fov / 180 * kPi) / w);
+    c.X = -c.s * w / 2;
+    c.Y = c.s * h / 2;
+    return c;
+}
+RT_HD int taps_of(int mode, int m) { return mode == RT_MODE_REF_1SPP ? 1 : mode == RT_MODE_REF_AA9 ? 9 : m * m; }
+// main.cpp:1241-1266; GRID: corner as in the AA path, taps at ((a+.5)/m*s, -(b+.5)/m*s)
+RT_HD v3 primary_dir(const Camera &c, int mode, int m, int i, int j, int k, float &weight) {
+    float s = c.s;
+    if (mode == RT_MODE_REF_1SPP) {
+        float dx = c.X + i * s + s / 2;
+        float dy = c.Y - j * s + s / 2;
+        weight = 1.0f;
+        return V3(dx, dy, 1);
+    }
+    float dx = c.X + i * s, dy = c.Y - j * s;
+    if (mode == RT_MODE_REF_AA9) {
+        int kx = k % 3, ky = k / 3;
+        float tx = dx + kx * s / 2;
+        float ty = dy - ky * s / 2;
+        weight = (float)((kx == 1 ? 2 : 1) * (ky == 1 ? 2 : 1));
+        return normalize(V3(tx, ty, 1));
+    }
+    int a = k % m, b = k / m;
+    float tx = dx + ((float)a + 0.5f) / (float)m * s;
+    float ty = dy - ((float)b + 0.5f) / (float)m * s;
+    weight = 1.0f;
+    return normalize(V3(tx, ty, 1));
+}
+// toneMapping, main.cpp:1184-1189
+RT_HD v3 tone_map(v3 c) {
+    float gamma = (float)(1.0 / 1.8);
+    return V3(clamp01(18.0f * powf(c.x, gamma)), clamp01(18.0f * powf(c.y, gamma)), clamp01(18.0f * powf(c.z, gamma)));
+}
+// Image::setPixel(vec3), Image.cpp:35-39: int = (float)(255 * c), truncation
+RT_HD uint8_t quantise(float c) { return (uint8_t)(int)(float)(255 * c); }
+
+// One pixel: all taps in order, weighted sum, normalisation (main.cpp:1243-1270)
+template <bool COUNT, class Stack>
+RT_HD v3 render_pixel(const DevScene &S, const Camera &cam, int mode, int grid_m, int max_depth, int accel,
+                      int i, int j, Stack &stk, Work &wk) {
+    int taps = taps_of(mode, grid_m);
+    if (mode == RT_MODE_REF_1SPP) {
+        float wt;
+        v3 dir = primary_dir(cam, mode, grid_m, i, j, 0, wt);
+        return trace<COUNT>(S, V3(0, 0, 0), dir, max_depth, accel, stk, wk, nullptr);
+    }
+    v3 color = V3(0, 0, 0);
+    for (int k = 0; k < taps; k++) {
+        float wt;
+        v3 dir = primary_dir(cam, mode, grid_m, i, j, k, wt);
+        v3 c = trace<COUNT>(S, V3(0, 0, 0), dir, max_depth, accel, stk, wk, nullptr);
+        color = color + c * wt;
+    }
+    return color / (mode == RT_MODE_REF_AA9 ? 16.f : (float)taps);
+}
+
+}  // namespace rtc

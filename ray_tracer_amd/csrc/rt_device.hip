@@ -1,0 +1,722 @@
+// rt_device.hip -- HIP kernels (gfx950) and the C ABI of librt_amd.so (include/rt_amd.h).
+//
+// Kernels:
+//   k_sort_keys / k_bitonic_step / k_gather_tris / k_children / k_fit   LBVH build, one per mesh
+//   k_render<COUNT>            one thread per pixel of a 16x16 tile, all taps, tile-major output
+//   k_untile                   tile-major shards -> row-major frame
+//   k_trace_rays / k_intersect_object   arbitrary-ray entry points used for parity checks
+//
+// There is no CPU path in this library: without a usable GPU every entry point fails.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "rt_amd.h"
+#include "rt_core.h"
+#include "rt_lbvh.h"
+#include "rt_prepare.h"
+
+using namespace rtc;
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kNumCounters = 10;
+
+// ------------------------------------------------------------------ traversal stack in LDS
+
+// One column of a [kStackDepth][kBlock] int array per thread: entry e of thread t lives at
+// e * kBlock + t, so a wave's accesses fall on 64 consecutive words (no bank conflicts).
+struct LdsStack {
+    int32_t *base;
+    int sp;
+    __device__ __forceinline__ void reset() { sp = 0; }
+    __device__ __forceinline__ bool empty() const { return sp == 0; }
+    __device__ __forceinline__ void push(int32_t v) {
+        if (sp < kStackDepth) { base[sp * kBlock] = v; sp++; }  // depth is validated at build time
+    }
+    __device__ __forceinline__ int32_t pop() { sp--; return base[sp * kBlock]; }
+};
+
+__device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+__device__ __forceinline__ void flush_work(const Work &wk, unsigned long long *counters, bool count) {
+    unsigned long long vals[kNumCounters] = {wk.rays_primary, wk.rays_shadow, wk.rays_secondary, wk.tri, wk.box,
+                                             wk.gate, wk.quadric, wk.plane, wk.shade, wk.tex};
+    int n = count ? kNumCounters : 3;
+    for (int i = 0; i < n; i++) {
+        unsigned long long s = wave_sum(vals[i]);
+        if ((threadIdx.x & 63) == 0 && s) atomicAdd(&counters[i], s);
+    }
+}
+
+// ------------------------------------------------------------------ LBVH build kernels
+
+__global__ void k_sort_keys(const float *tri_pos, int n, int n_pow2, const float *lo, const float *hi,
+                            unsigned long long *keys) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pow2) return;
+    float l[3] = {lo[0], lo[1], lo[2]}, h[3] = {hi[0], hi[1], hi[2]};
+    keys[i] = i < n ? tri_sort_key(tri_pos + 9 * (size_t)i, l, h, (uint32_t)i) : ~0ull;
+}
+
+// one compare-exchange step (j, k) of a bitonic sorting network over n_pow2 keys
+__global__ void k_bitonic_step(unsigned long long *keys, int n_pow2, int j, int k) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pow2) return;
+    int partner = i ^ j;
+    if (partner > i) {
+        unsigned long long a = keys[i], b = keys[partner];
+        bool up = (i & k) == 0;
+        if ((a > b) == up) { keys[i] = b; keys[partner] = a; }
+    }
+}
+
+// sorted position -> triangle record, tie-break key and original index (keys == nullptr: identity order)
+__global__ void k_gather_tris(const unsigned long long *keys, int n, int tri_offset, const float *tri_pos,
+                              const int32_t *tri_frag, const int32_t *tri_sub, f4 *tri_test, uint32_t *tri_key,
+                              int32_t *tri_orig) {
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    int local = keys ? (int)(uint32_t)(keys[k] & 0xffffffffull) : k;
+    int orig = tri_offset + local;
+    make_tri_test(tri_pos + 9 * (size_t)orig, tri_test + 3 * (size_t)(tri_offset + k));
+    tri_key[tri_offset + k] = 2u * (uint32_t)tri_frag[orig] + (1u - (uint32_t)tri_sub[orig]);
+    tri_orig[tri_offset + k] = orig;
+}
+
+__global__ void k_children(const unsigned long long *keys, int n, int32_t *c0, int32_t *c1) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n - 1) return;
+    int32_t a, b;
+    lbvh_node_children(reinterpret_cast<const uint64_t *>(keys), n, i, a, b);
+    c0[i] = a;
+    c1[i] = b;
+}
+
+// Bottom-up fit by ONE workgroup: pass p completes every node whose children were completed in an
+// earlier pass; done_pass[i] holds the pass number (0 = not yet).  All traffic stays inside one CU,
+// so a workgroup barrier is enough to order a pass after the previous one.
+__global__ __launch_bounds__(1024) void k_fit(int n, const int32_t *c0s, const int32_t *c1s, const f4 *tt, float pad,
+                                              int32_t *done_pass, float *node_lo, float *node_hi, int32_t *height,
+                                              BvhNode *nodes, int32_t *root_height) {
+    __shared__ int s_left;
+    int n_int = n - 1;
+    for (int i = threadIdx.x; i < n_int; i += blockDim.x) done_pass[i] = 0;
+    __syncthreads();
+    for (int pass = 1; pass <= 4096; pass++) {
+        if (threadIdx.x == 0) s_left = 0;
+        __syncthreads();
+        int left = 0;
+        for (int i = threadIdx.x; i < n_int; i += blockDim.x)
+            if (lbvh_fit_node(i, pass, c0s, c1s, tt, pad, done_pass, node_lo, node_hi, height, nodes) == 2) left++;
+        if (left) atomicAdd(&s_left, left);
+        __threadfence_block();
+        __syncthreads();
+        int remaining = s_left;
+        __syncthreads();
+        if (remaining == 0) break;
+    }
+    if (threadIdx.x == 0) *root_height = n_int > 0 ? height[0] : 0;
+}
+
+// ------------------------------------------------------------------ render kernels
+
+struct RenderArgs {
+    int32_t width, height, mode, grid_m, max_depth, accel, rank, world_size;
+    int32_t tiles_x, tiles_total;
+    Camera cam;
+};
+
+// Block b renders local tile b = global tile b * world_size + rank.  Each wave owns an 8x8 pixel
+// quadrant of the 16x16 tile so that its 64 rays are spatially coherent.
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) void k_render(DevScene S, RenderArgs a, float *rgb_tiles, uint8_t *rgb8_tiles,
+                                                   unsigned long long *counters) {
+    __shared__ int32_t lds_stack[kStackDepth * kBlock];
+    LdsStack stk;
+    stk.base = lds_stack + threadIdx.x;
+    stk.sp = 0;
+    int tile = blockIdx.x * a.world_size + a.rank;
+    int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int px = (wave & 1) * 8 + (lane & 7), py = (wave >> 1) * 8 + (lane >> 3);
+    int i = (tile % a.tiles_x) * RT_TILE_W + px, j = (tile / a.tiles_x) * RT_TILE_H + py;
+    Work wk;
+    work_zero(wk);
+    v3 color = V3(0, 0, 0);
+    bool inside = tile < a.tiles_total && i < a.width && j < a.height;
+    if (inside) color = render_pixel<COUNT>(S, a.cam, a.mode, a.grid_m, a.max_depth, a.accel, i, j, stk, wk);
+    size_t p = ((size_t)blockIdx.x * (RT_TILE_W * RT_TILE_H) + (size_t)py * RT_TILE_W + px) * 3;
+    if (rgb_tiles) { rgb_tiles[p] = color.x; rgb_tiles[p + 1] = color.y; rgb_tiles[p + 2] = color.z; }
+    if (rgb8_tiles) {
+        v3 t = tone_map(color);
+        rgb8_tiles[p] = inside ? quantise(t.x) : 0;
+        rgb8_tiles[p + 1] = inside ? quantise(t.y) : 0;
+        rgb8_tiles[p + 2] = inside ? quantise(t.z) : 0;
+    }
+    flush_work(wk, counters, COUNT);
+}
+
+// shards[r][local_tile][16][16][3] -> frame[y][x][3]; first_rank/n_ranks select which shards exist
+template <typename T>
+__global__ void k_untile(const T *shards, T *frame, int width, int height, int tiles_x, int tiles_total,
+                         int tiles_per_rank, int world_size, int first_rank, int n_ranks) {
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t per_tile = RT_TILE_W * RT_TILE_H;
+    size_t total = (size_t)n_ranks * tiles_per_rank * per_tile;
+    if (idx >= total) return;
+    int within = (int)(idx % per_tile);
+    size_t tl = idx / per_tile;
+    int local = (int)(tl % tiles_per_rank), r = (int)(tl / tiles_per_rank) + first_rank;
+    int tile = local * world_size + r;
+    if (tile >= tiles_total) return;
+    int x = (tile % tiles_x) * RT_TILE_W + within % RT_TILE_W, y = (tile / tiles_x) * RT_TILE_H + within / RT_TILE_W;
+    if (x >= width || y >= height) return;
+    const T *src = shards + idx * 3;
+    T *dst = frame + ((size_t)y * width + x) * 3;
+    dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2];
+}
+
+__global__ __launch_bounds__(kBlock) void k_trace_rays(DevScene S, long long n, const float *o, const float *d,
+                                                       int max_depth, int accel, rt_hit_record *hits, float *radiance,
+                                                       unsigned long long *counters) {
+    __shared__ int32_t lds_stack[kStackDepth * kBlock];
+    LdsStack stk;
+    stk.base = lds_stack + threadIdx.x;
+    stk.sp = 0;
+    long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    Work wk;
+    work_zero(wk);
+    if (r < n) {
+        rt_hit_record h;
+        v3 c = trace<false>(S, ld3(o + 3 * r), ld3(d + 3 * r), max_depth, accel, stk, wk, hits ? &h : nullptr);
+        if (hits) hits[r] = h;
+        if (radiance) { radiance[3 * r] = c.x; radiance[3 * r + 1] = c.y; radiance[3 * r + 2] = c.z; }
+    }
+    flush_work(wk, counters, false);
+}
+
+__global__ __launch_bounds__(kBlock) void k_intersect_object(DevScene S, int object, long long n, const float *o,
+                                                             const float *d, int accel, rt_hit_record *hits) {
+    __shared__ int32_t lds_stack[kStackDepth * kBlock];
+    LdsStack stk;
+    stk.base = lds_stack + threadIdx.x;
+    stk.sp = 0;
+    long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    Work wk;
+    work_zero(wk);
+    rt_hit_record h;
+    intersect_object<false>(S, object, ld3(o + 3 * r), ld3(d + 3 * r), accel, h, stk, wk);
+    hits[r] = h;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------ context
+
+struct rt_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;      // the stream in use
+    hipStream_t own_stream = nullptr;  // created with the context
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::string err;
+    bool uploaded = false, built = false;
+    std::vector<void *> allocs;  // everything owned by the current scene
+    DevScene S{};
+    std::vector<DevMesh> meshes;
+    std::vector<MeshBuild> mesh_build;
+    int n_triangles = 0, n_meshes = 0, n_nodes = 0;
+    // device arrays the build writes
+    float *d_tri_pos = nullptr;
+    f4 *d_tri_test = nullptr;
+    uint32_t *d_tri_key = nullptr;
+    int32_t *d_tri_orig = nullptr;
+    int32_t *d_tri_frag = nullptr, *d_tri_sub = nullptr;
+    BvhNode *d_nodes = nullptr;
+    DevMesh *d_meshes = nullptr;
+    unsigned long long *d_counters = nullptr;
+    float last_trace_ms = 0, last_build_ms = 0;
+    int bvh_max_depth = 0;
+};
+
+#define RT_HIP(call)                                                                             \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess) {                                                                  \
+            ctx->err = std::string(#call) + ": " + hipGetErrorString(e_);                        \
+            return RT_ERR_HIP;                                                                   \
+        }                                                                                        \
+    } while (0)
+
+static int fail(rt_ctx *ctx, int code, const std::string &msg) {
+    if (ctx) ctx->err = msg;
+    return code;
+}
+
+template <typename T>
+static int dev_alloc(rt_ctx *ctx, T **out, size_t count, const void *src, bool scene_owned = true) {
+    *out = nullptr;
+    size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+    void *p = nullptr;
+    RT_HIP(hipMalloc(&p, bytes));
+    if (scene_owned) ctx->allocs.push_back(p);
+    if (src && count) RT_HIP(hipMemcpyAsync(p, src, count * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+    else RT_HIP(hipMemsetAsync(p, 0, bytes, ctx->stream));
+    *out = static_cast<T *>(p);
+    return RT_OK;
+}
+
+static void free_scene(rt_ctx *ctx) {
+    for (void *p : ctx->allocs) (void)hipFree(p);
+    ctx->allocs.clear();
+    ctx->uploaded = ctx->built = false;
+    ctx->meshes.clear();
+    ctx->mesh_build.clear();
+    ctx->S = DevScene{};
+}
+
+extern "C" int rt_context_create(int device, rt_ctx **out) {
+    if (!out) return RT_ERR_INVALID;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return RT_ERR_NO_DEVICE;
+    if (device < 0 || device >= count) return RT_ERR_INVALID;
+    rt_ctx *ctx = new rt_ctx();
+    ctx->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&ctx->own_stream) != hipSuccess ||
+        hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
+        delete ctx;
+        return RT_ERR_HIP;
+    }
+    ctx->stream = ctx->own_stream;
+    void *c = nullptr;
+    if (hipMalloc(&c, kNumCounters * sizeof(unsigned long long)) != hipSuccess ||
+        hipMemset(c, 0, kNumCounters * sizeof(unsigned long long)) != hipSuccess) {
+        delete ctx;
+        return RT_ERR_HIP;
+    }
+    ctx->d_counters = static_cast<unsigned long long *>(c);
+    *out = ctx;
+    return RT_OK;
+}
+
+extern "C" int rt_context_destroy(rt_ctx *ctx) {
+    if (!ctx) return RT_ERR_INVALID;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    free_scene(ctx);
+    (void)hipFree(ctx->d_counters);
+    (void)hipEventDestroy(ctx->ev0);
+    (void)hipEventDestroy(ctx->ev1);
+    (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+    return RT_OK;
+}
+
+extern "C" const char *rt_last_error(const rt_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+extern "C" void *rt_stream(rt_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+extern "C" int rt_set_stream(rt_ctx *ctx, void *hip_stream) {
+    if (!ctx) return RT_ERR_INVALID;
+    RT_HIP(hipSetDevice(ctx->device));
+    RT_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+    return RT_OK;
+}
+
+extern "C" int rt_sync(rt_ctx *ctx) {
+    if (!ctx) return RT_ERR_INVALID;
+    RT_HIP(hipSetDevice(ctx->device));
+    RT_HIP(hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+extern "C" int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *sc) {
+    if (!ctx || !sc) return RT_ERR_INVALID;
+    RT_HIP(hipSetDevice(ctx->device));
+    std::string bad = validate_scene(sc);
+    if (!bad.empty()) return fail(ctx, RT_ERR_INVALID, bad);
+    RT_HIP(hipStreamSynchronize(ctx->stream));
+    free_scene(ctx);
+
+    int rc;
+    rt_object *d_objects; rt_sphere *d_spheres; rt_plane *d_planes; rt_cone *d_cones; rt_material *d_materials;
+    float *d_lp, *d_lc, *d_nrm, *d_uv; int32_t *d_tmat;
+    if ((rc = dev_alloc(ctx, &d_objects, sc->n_objects, sc->objects))) return rc;
+    if ((rc = dev_alloc(ctx, &d_spheres, sc->n_spheres, sc->spheres))) return rc;
+    if ((rc = dev_alloc(ctx, &d_planes, sc->n_planes, sc->planes))) return rc;
+    if ((rc = dev_alloc(ctx, &d_cones, sc->n_cones, sc->cones))) return rc;
+    if ((rc = dev_alloc(ctx, &d_materials, sc->n_materials, sc->materials))) return rc;
+    if ((rc = dev_alloc(ctx, &d_lp, 3 * (size_t)sc->n_lights, sc->light_pos))) return rc;
+    if ((rc = dev_alloc(ctx, &d_lc, 3 * (size_t)sc->n_lights, sc->light_color))) return rc;
+    size_t nt = sc->n_triangles;
+    if ((rc = dev_alloc(ctx, &ctx->d_tri_pos, 9 * nt, sc->tri_pos))) return rc;
+    if ((rc = dev_alloc(ctx, &d_nrm, 9 * nt, sc->tri_nrm))) return rc;
+    if ((rc = dev_alloc(ctx, &d_uv, 6 * nt, sc->tri_uv))) return rc;
+    if ((rc = dev_alloc(ctx, &d_tmat, nt, sc->tri_material))) return rc;
+    if ((rc = dev_alloc(ctx, &ctx->d_tri_frag, nt, sc->tri_frag))) return rc;
+    if ((rc = dev_alloc(ctx, &ctx->d_tri_sub, nt, sc->tri_sub))) return rc;
+    if ((rc = dev_alloc(ctx, &ctx->d_tri_test, 3 * nt, (const void *)nullptr))) return rc;
+    if ((rc = dev_alloc(ctx, &ctx->d_tri_key, nt, (const void *)nullptr))) return rc;
+    if ((rc = dev_alloc(ctx, &ctx->d_tri_orig, nt, (const void *)nullptr))) return rc;
+
+    // textures
+    std::vector<DevTexture> tex(sc->n_textures);
+    for (int i = 0; i < sc->n_textures; i++) {
+        const rt_texture &t = sc->textures[i];
+        tex[i].kind = t.kind; tex[i].w = t.width; tex[i].h = t.height; tex[i].pad = 0;
+        for (int k = 0; k < 4; k++) tex[i].maps[k] = nullptr;
+        if (t.kind == RT_TEX_IMAGE) {
+            const uint8_t *src[4] = {t.base_color, t.normal, t.occlusion, t.roughness};
+            for (int k = 0; k < 4; k++) {
+                uint8_t *d;
+                if ((rc = dev_alloc(ctx, &d, (size_t)t.width * t.height * 4, src[k]))) return rc;
+                tex[i].maps[k] = d;
+            }
+        }
+    }
+    DevTexture *d_tex;
+    if ((rc = dev_alloc(ctx, &d_tex, tex.size(), tex.data()))) return rc;
+
+    // meshes: bounds, padding, gate triangles, node ranges
+    ctx->n_meshes = sc->n_meshes;
+    ctx->n_triangles = sc->n_triangles;
+    std::vector<f4> gate;
+    int node_total = prepare_meshes(sc, ctx->meshes, ctx->mesh_build, gate);
+    ctx->n_nodes = node_total;
+    f4 *d_gate;
+    if ((rc = dev_alloc(ctx, &d_gate, gate.size(), gate.data()))) return rc;
+    if ((rc = dev_alloc(ctx, &ctx->d_nodes, (size_t)node_total, (const void *)nullptr))) return rc;
+    if ((rc = dev_alloc(ctx, &ctx->d_meshes, ctx->meshes.size(), ctx->meshes.data()))) return rc;
+
+    // identity triangle order: valid for RT_ACCEL_BRUTE until rt_build_accel sorts it
+    for (int i = 0; i < sc->n_meshes; i++) {
+        const rt_mesh &m = sc->meshes[i];
+        if (m.tri_count <= 0) continue;
+        hipLaunchKernelGGL(k_gather_tris, dim3((m.tri_count + 255) / 256), dim3(256), 0, ctx->stream, nullptr, m.tri_count,
+                           m.tri_offset, ctx->d_tri_pos, ctx->d_tri_frag, ctx->d_tri_sub, ctx->d_tri_test, ctx->d_tri_key,
+                           ctx->d_tri_orig);
+    }
+    RT_HIP(hipGetLastError());
+
+    DevScene &S = ctx->S;
+    S.n_objects = sc->n_objects; S.n_lights = sc->n_lights;
+    S.objects = d_objects; S.spheres = d_spheres; S.planes = d_planes; S.cones = d_cones; S.meshes = ctx->d_meshes;
+    S.tri_test = ctx->d_tri_test; S.tri_key = ctx->d_tri_key; S.tri_orig = ctx->d_tri_orig;
+    S.tri_nrm = d_nrm; S.tri_uv = d_uv; S.tri_material = d_tmat; S.tri_frag = ctx->d_tri_frag; S.tri_sub = ctx->d_tri_sub;
+    S.gate_tri = d_gate; S.nodes = ctx->d_nodes; S.materials = d_materials; S.textures = d_tex;
+    S.light_pos = d_lp; S.light_color = d_lc;
+    for (int a = 0; a < 3; a++) S.ambient[a] = sc->ambient[a];
+    RT_HIP(hipStreamSynchronize(ctx->stream));  // the caller's arrays may go away after return
+    ctx->uploaded = true;
+    ctx->built = false;
+    return RT_OK;
+}
+
+extern "C" int rt_build_accel(rt_ctx *ctx) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (!ctx->uploaded) return fail(ctx, RT_ERR_STATE, "rt_build_accel before rt_scene_upload");
+    if (ctx->built) return RT_OK;
+    RT_HIP(hipSetDevice(ctx->device));
+    int max_n = 0;
+    for (const DevMesh &m : ctx->meshes) max_n = std::max(max_n, m.tri_count);
+    int max_pow2 = 1;
+    while (max_pow2 < max_n) max_pow2 <<= 1;
+    unsigned long long *d_keys = nullptr;
+    int32_t *d_c0 = nullptr, *d_c1 = nullptr, *d_done = nullptr, *d_height = nullptr, *d_root = nullptr;
+    float *d_lo = nullptr, *d_hi = nullptr, *d_bounds = nullptr;
+    int rc;
+    std::vector<void *> tmp;
+    auto cleanup = [&]() { for (void *p : tmp) (void)hipFree(p); };
+#define TMP_ALLOC(ptr, count)                                                    \
+    if ((rc = dev_alloc(ctx, &ptr, (count), (const void *)nullptr, false))) { cleanup(); return rc; } \
+    tmp.push_back(ptr)
+    TMP_ALLOC(d_keys, (size_t)max_pow2);
+    TMP_ALLOC(d_c0, (size_t)max_n);
+    TMP_ALLOC(d_c1, (size_t)max_n);
+    TMP_ALLOC(d_done, (size_t)max_n);
+    TMP_ALLOC(d_height, (size_t)max_n);
+    TMP_ALLOC(d_root, (size_t)ctx->meshes.size() + 1);
+    TMP_ALLOC(d_lo, 3 * (size_t)max_n);
+    TMP_ALLOC(d_hi, 3 * (size_t)max_n);
+    TMP_ALLOC(d_bounds, 6 * (size_t)ctx->meshes.size() + 6);
+#undef TMP_ALLOC
+    std::vector<float> bounds(6 * ctx->meshes.size() + 6, 0.0f);
+    for (size_t i = 0; i < ctx->meshes.size(); i++)
+        for (int a = 0; a < 3; a++) { bounds[6 * i + a] = ctx->mesh_build[i].lo[a]; bounds[6 * i + 3 + a] = ctx->mesh_build[i].hi[a]; }
+    hipError_t e = hipMemcpyAsync(d_bounds, bounds.data(), bounds.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+    if (e != hipSuccess) { cleanup(); return fail(ctx, RT_ERR_HIP, hipGetErrorString(e)); }
+
+    (void)hipEventRecord(ctx->ev0, ctx->stream);
+    for (size_t i = 0; i < ctx->meshes.size(); i++) {
+        const DevMesh &m = ctx->meshes[i];
+        int n = m.tri_count;
+        if (n <= 0) continue;
+        int n_pow2 = 1;
+        while (n_pow2 < n) n_pow2 <<= 1;
+        dim3 blk(256), grd((n_pow2 + 255) / 256);
+        hipLaunchKernelGGL(k_sort_keys, grd, blk, 0, ctx->stream, ctx->d_tri_pos + 9 * (size_t)m.tri_offset, n, n_pow2,
+                           d_bounds + 6 * i, d_bounds + 6 * i + 3, d_keys);
+        for (int k = 2; k <= n_pow2; k <<= 1)
+            for (int j = k >> 1; j > 0; j >>= 1)
+                hipLaunchKernelGGL(k_bitonic_step, grd, blk, 0, ctx->stream, d_keys, n_pow2, j, k);
+        hipLaunchKernelGGL(k_gather_tris, dim3((n + 255) / 256), blk, 0, ctx->stream, d_keys, n, m.tri_offset, ctx->d_tri_pos,
+                           ctx->d_tri_frag, ctx->d_tri_sub, ctx->d_tri_test, ctx->d_tri_key, ctx->d_tri_orig);
+        if (n >= 2) {
+            hipLaunchKernelGGL(k_children, dim3((n + 255) / 256), blk, 0, ctx->stream, d_keys, n, d_c0, d_c1);
+            hipLaunchKernelGGL(k_fit, dim3(1), dim3(1024), 0, ctx->stream, n, d_c0, d_c1,
+                               ctx->d_tri_test + 3 * (size_t)m.tri_offset, ctx->mesh_build[i].pad, d_done, d_lo, d_hi, d_height,
+                               ctx->d_nodes + m.node_offset, d_root + i);
+        }
+    }
+    (void)hipEventRecord(ctx->ev1, ctx->stream);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    std::vector<int32_t> roots(ctx->meshes.size() + 1, 0);
+    if (e == hipSuccess) e = hipMemcpy(roots.data(), d_root, roots.size() * sizeof(int32_t), hipMemcpyDeviceToHost);
+    cleanup();
+    if (e != hipSuccess) return fail(ctx, RT_ERR_HIP, std::string("LBVH build: ") + hipGetErrorString(e));
+    (void)hipEventElapsedTime(&ctx->last_build_ms, ctx->ev0, ctx->ev1);
+    ctx->bvh_max_depth = 0;
+    for (size_t i = 0; i < ctx->meshes.size(); i++) {
+        ctx->mesh_build[i].height = roots[i];
+        ctx->bvh_max_depth = std::max(ctx->bvh_max_depth, roots[i]);
+    }
+    if (ctx->bvh_max_depth > kStackDepth)
+        return fail(ctx, RT_ERR_LIMIT, "LBVH height " + std::to_string(ctx->bvh_max_depth) + " exceeds the traversal stack (" +
+                                           std::to_string(kStackDepth) + ")");
+    ctx->built = true;
+    return RT_OK;
+}
+
+// ------------------------------------------------------------------ rendering
+
+static int check_params(rt_ctx *ctx, const rt_render_params *p) {
+    if (!p) return RT_ERR_INVALID;
+    if (p->width <= 0 || p->height <= 0 || p->width > 65536 || p->height > 65536) return fail(ctx, RT_ERR_INVALID, "bad frame size");
+    if (p->mode < RT_MODE_REF_1SPP || p->mode > RT_MODE_GRID) return fail(ctx, RT_ERR_INVALID, "bad sampling mode");
+    if (p->mode == RT_MODE_GRID && (p->grid_m < 1 || p->grid_m > 64)) return fail(ctx, RT_ERR_INVALID, "grid_m out of range");
+    if (p->max_depth < 0 || p->max_depth > RT_MAX_DEPTH) return fail(ctx, RT_ERR_INVALID, "max_depth out of range");
+    if (p->accel != RT_ACCEL_LBVH && p->accel != RT_ACCEL_BRUTE) return fail(ctx, RT_ERR_INVALID, "bad accel");
+    if (p->world_size < 1 || p->rank < 0 || p->rank >= p->world_size) return fail(ctx, RT_ERR_INVALID, "bad rank/world_size");
+    if (!(p->fov > 0 && p->fov < 180)) return fail(ctx, RT_ERR_INVALID, "bad fov");
+    return RT_OK;
+}
+
+extern "C" int rt_shard_tiles(const rt_render_params *p, int32_t *tiles_per_rank, int32_t *tiles_total) {
+    if (!p || p->width <= 0 || p->height <= 0 || p->world_size < 1) return RT_ERR_INVALID;
+    int tx = (p->width + RT_TILE_W - 1) / RT_TILE_W, ty = (p->height + RT_TILE_H - 1) / RT_TILE_H;
+    int total = tx * ty;
+    if (tiles_total) *tiles_total = total;
+    if (tiles_per_rank) *tiles_per_rank = (total + p->world_size - 1) / p->world_size;
+    return RT_OK;
+}
+
+static int ready_for(rt_ctx *ctx, int accel) {
+    if (!ctx->uploaded) return fail(ctx, RT_ERR_STATE, "no scene uploaded");
+    if (accel == RT_ACCEL_LBVH && !ctx->built && ctx->n_triangles > 0)
+        return fail(ctx, RT_ERR_STATE, "RT_ACCEL_LBVH requested before rt_build_accel");
+    return RT_OK;
+}
+
+extern "C" int rt_render_shard_device(rt_ctx *ctx, const rt_render_params *p, float *d_rgb_tiles, uint8_t *d_rgb8_tiles) {
+    if (!ctx) return RT_ERR_INVALID;
+    int rc = check_params(ctx, p);
+    if (rc) return rc;
+    if ((rc = ready_for(ctx, p->accel))) return rc;
+    RT_HIP(hipSetDevice(ctx->device));
+    RenderArgs a;
+    a.width = p->width; a.height = p->height; a.mode = p->mode; a.grid_m = p->grid_m; a.max_depth = p->max_depth;
+    a.accel = p->accel; a.rank = p->rank; a.world_size = p->world_size;
+    a.tiles_x = (p->width + RT_TILE_W - 1) / RT_TILE_W;
+    int ty = (p->height + RT_TILE_H - 1) / RT_TILE_H;
+    a.tiles_total = a.tiles_x * ty;
+    a.cam = make_camera(p->width, p->height, p->fov);
+    int local_tiles = (a.tiles_total - p->rank + p->world_size - 1) / p->world_size;  // tiles t = b*W + rank < total
+    if (local_tiles <= 0) return RT_OK;
+    RT_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+    if (p->count_work)
+        hipLaunchKernelGGL(k_render<true>, dim3(local_tiles), dim3(kBlock), 0, ctx->stream, ctx->S, a, d_rgb_tiles, d_rgb8_tiles, ctx->d_counters);
+    else
+        hipLaunchKernelGGL(k_render<false>, dim3(local_tiles), dim3(kBlock), 0, ctx->stream, ctx->S, a, d_rgb_tiles, d_rgb8_tiles, ctx->d_counters);
+    RT_HIP(hipGetLastError());
+    RT_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+    return RT_OK;
+}
+
+extern "C" int rt_untile_device(rt_ctx *ctx, const rt_render_params *p, const float *d_rgb_shards, float *d_rgb_frame,
+                                const uint8_t *d_rgb8_shards, uint8_t *d_rgb8_frame) {
+    if (!ctx) return RT_ERR_INVALID;
+    int rc = check_params(ctx, p);
+    if (rc) return rc;
+    RT_HIP(hipSetDevice(ctx->device));
+    int per_rank, total;
+    rt_shard_tiles(p, &per_rank, &total);
+    int tiles_x = (p->width + RT_TILE_W - 1) / RT_TILE_W;
+    size_t elems = (size_t)p->world_size * per_rank * RT_TILE_W * RT_TILE_H;
+    dim3 blk(256), grd((unsigned)((elems + 255) / 256));
+    if (d_rgb_shards && d_rgb_frame)
+        hipLaunchKernelGGL(k_untile<float>, grd, blk, 0, ctx->stream, d_rgb_shards, d_rgb_frame, p->width, p->height, tiles_x, total,
+                           per_rank, p->world_size, 0, p->world_size);
+    if (d_rgb8_shards && d_rgb8_frame)
+        hipLaunchKernelGGL(k_untile<uint8_t>, grd, blk, 0, ctx->stream, d_rgb8_shards, d_rgb8_frame, p->width, p->height, tiles_x,
+                           total, per_rank, p->world_size, 0, p->world_size);
+    RT_HIP(hipGetLastError());
+    return RT_OK;
+}
+
+extern "C" int rt_render(rt_ctx *ctx, const rt_render_params *p, float *rgb_linear, uint8_t *rgb8) {
+    if (!ctx) return RT_ERR_INVALID;
+    int rc = check_params(ctx, p);
+    if (rc) return rc;
+    if ((rc = ready_for(ctx, p->accel))) return rc;
+    RT_HIP(hipSetDevice(ctx->device));
+    int per_rank, total;
+    rt_shard_tiles(p, &per_rank, &total);
+    size_t shard_elems = (size_t)per_rank * RT_TILE_W * RT_TILE_H * 3;
+    size_t frame_elems = (size_t)p->width * p->height * 3;
+    float *d_tiles = nullptr, *d_frame = nullptr;
+    uint8_t *d_tiles8 = nullptr, *d_frame8 = nullptr;
+    std::vector<void *> tmp;
+    auto cleanup = [&]() { for (void *q : tmp) (void)hipFree(q); };
+    auto alloc = [&](void **ptr, size_t bytes) -> bool {
+        if (hipMalloc(ptr, bytes) != hipSuccess) return false;
+        tmp.push_back(*ptr);
+        return hipMemsetAsync(*ptr, 0, bytes, ctx->stream) == hipSuccess;
+    };
+    bool ok = true;
+    if (rgb_linear) ok = ok && alloc((void **)&d_tiles, shard_elems * sizeof(float)) && alloc((void **)&d_frame, frame_elems * sizeof(float));
+    if (rgb8) ok = ok && alloc((void **)&d_tiles8, shard_elems) && alloc((void **)&d_frame8, frame_elems);
+    if (!ok) { cleanup(); return fail(ctx, RT_ERR_HIP, "rt_render: device allocation failed"); }
+    rc = rt_render_shard_device(ctx, p, d_tiles, d_tiles8);
+    if (rc == RT_OK) {
+        int tiles_x = (p->width + RT_TILE_W - 1) / RT_TILE_W;
+        size_t elems = (size_t)per_rank * RT_TILE_W * RT_TILE_H;
+        dim3 blk(256), grd((unsigned)((elems + 255) / 256));
+        if (d_tiles)
+            hipLaunchKernelGGL(k_untile<float>, grd, blk, 0, ctx->stream, d_tiles, d_frame, p->width, p->height, tiles_x, total, per_rank,
+                               p->world_size, p->rank, 1);
+        if (d_tiles8)
+            hipLaunchKernelGGL(k_untile<uint8_t>, grd, blk, 0, ctx->stream, d_tiles8, d_frame8, p->width, p->height, tiles_x, total,
+                               per_rank, p->world_size, p->rank, 1);
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess && rgb_linear) e = hipMemcpyAsync(rgb_linear, d_frame, frame_elems * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess && rgb8) e = hipMemcpyAsync(rgb8, d_frame8, frame_elems, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) rc = fail(ctx, RT_ERR_HIP, std::string("rt_render: ") + hipGetErrorString(e));
+        else (void)hipEventElapsedTime(&ctx->last_trace_ms, ctx->ev0, ctx->ev1);
+    }
+    cleanup();
+    return rc;
+}
+
+extern "C" int rt_trace_rays(rt_ctx *ctx, int64_t n, const float *o, const float *d, int32_t max_depth, int32_t accel,
+                             rt_hit_record *hits, float *radiance) {
+    if (!ctx || n < 0 || (n > 0 && (!o || !d))) return RT_ERR_INVALID;
+    if (max_depth < 0 || max_depth > RT_MAX_DEPTH) return fail(ctx, RT_ERR_INVALID, "max_depth out of range");
+    if (accel != RT_ACCEL_LBVH && accel != RT_ACCEL_BRUTE) return fail(ctx, RT_ERR_INVALID, "bad accel");
+    int rc = ready_for(ctx, accel);
+    if (rc) return rc;
+    if (n == 0) return RT_OK;
+    RT_HIP(hipSetDevice(ctx->device));
+    float *d_o = nullptr, *d_d = nullptr, *d_rad = nullptr;
+    rt_hit_record *d_hits = nullptr;
+    std::vector<void *> tmp;
+    auto cleanup = [&]() { for (void *q : tmp) (void)hipFree(q); };
+    hipError_t e = hipMalloc((void **)&d_o, 3 * n * sizeof(float));
+    if (e == hipSuccess) { tmp.push_back(d_o); e = hipMalloc((void **)&d_d, 3 * n * sizeof(float)); }
+    if (e == hipSuccess) { tmp.push_back(d_d); if (radiance) { e = hipMalloc((void **)&d_rad, 3 * n * sizeof(float)); if (e == hipSuccess) tmp.push_back(d_rad); } }
+    if (e == hipSuccess && hits) { e = hipMalloc((void **)&d_hits, n * sizeof(rt_hit_record)); if (e == hipSuccess) tmp.push_back(d_hits); }
+    if (e == hipSuccess) e = hipMemcpyAsync(d_o, o, 3 * n * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_d, d, 3 * n * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_trace_rays, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, ctx->S, (long long)n,
+                           d_o, d_d, max_depth, accel, d_hits, d_rad, ctx->d_counters);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess && radiance) e = hipMemcpyAsync(radiance, d_rad, 3 * n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && hits) e = hipMemcpyAsync(hits, d_hits, n * sizeof(rt_hit_record), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    cleanup();
+    if (e != hipSuccess) return fail(ctx, RT_ERR_HIP, std::string("rt_trace_rays: ") + hipGetErrorString(e));
+    return RT_OK;
+}
+
+extern "C" int rt_intersect_object(rt_ctx *ctx, int32_t object, int64_t n, const float *o, const float *d, int32_t accel,
+                                   rt_hit_record *hits) {
+    if (!ctx || n < 0 || (n > 0 && (!o || !d || !hits))) return RT_ERR_INVALID;
+    if (accel != RT_ACCEL_LBVH && accel != RT_ACCEL_BRUTE) return fail(ctx, RT_ERR_INVALID, "bad accel");
+    int rc = ready_for(ctx, accel);
+    if (rc) return rc;
+    if (object < 0 || object >= ctx->S.n_objects) return fail(ctx, RT_ERR_INVALID, "object index out of range");
+    if (n == 0) return RT_OK;
+    RT_HIP(hipSetDevice(ctx->device));
+    float *d_o = nullptr, *d_d = nullptr;
+    rt_hit_record *d_hits = nullptr;
+    std::vector<void *> tmp;
+    auto cleanup = [&]() { for (void *q : tmp) (void)hipFree(q); };
+    hipError_t e = hipMalloc((void **)&d_o, 3 * n * sizeof(float));
+    if (e == hipSuccess) { tmp.push_back(d_o); e = hipMalloc((void **)&d_d, 3 * n * sizeof(float)); }
+    if (e == hipSuccess) { tmp.push_back(d_d); e = hipMalloc((void **)&d_hits, n * sizeof(rt_hit_record)); }
+    if (e == hipSuccess) { tmp.push_back(d_hits); e = hipMemcpyAsync(d_o, o, 3 * n * sizeof(float), hipMemcpyHostToDevice, ctx->stream); }
+    if (e == hipSuccess) e = hipMemcpyAsync(d_d, d, 3 * n * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_intersect_object, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, ctx->S, object,
+                           (long long)n, d_o, d_d, accel, d_hits);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(hits, d_hits, n * sizeof(rt_hit_record), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    cleanup();
+    if (e != hipSuccess) return fail(ctx, RT_ERR_HIP, std::string("rt_intersect_object: ") + hipGetErrorString(e));
+    return RT_OK;
+}
+
+extern "C" int rt_get_counters(rt_ctx *ctx, rt_counters *out) {
+    if (!ctx || !out) return RT_ERR_INVALID;
+    RT_HIP(hipSetDevice(ctx->device));
+    RT_HIP(hipStreamSynchronize(ctx->stream));
+    unsigned long long c[kNumCounters];
+    RT_HIP(hipMemcpy(c, ctx->d_counters, sizeof c, hipMemcpyDeviceToHost));
+    std::memset(out, 0, sizeof *out);
+    out->rays_primary = c[0]; out->rays_shadow = c[1]; out->rays_secondary = c[2];
+    out->tri_tests = c[3]; out->box_tests = c[4]; out->gate_tests = c[5]; out->quadric_tests = c[6];
+    out->plane_tests = c[7]; out->shade_evals = c[8]; out->tex_fetches = c[9];
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) == hipSuccess) ctx->last_trace_ms = ms;
+    out->last_trace_ms = ctx->last_trace_ms;
+    out->last_build_ms = ctx->last_build_ms;
+    out->bvh_max_depth = ctx->bvh_max_depth;
+    return RT_OK;
+}
+
+extern "C" int rt_reset_counters(rt_ctx *ctx) {
+    if (!ctx) return RT_ERR_INVALID;
+    RT_HIP(hipSetDevice(ctx->device));
+    RT_HIP(hipMemsetAsync(ctx->d_counters, 0, kNumCounters * sizeof(unsigned long long), ctx->stream));
+    return RT_OK;
+}
+
+extern "C" int rt_debug_copy_bvh(rt_ctx *ctx, int32_t mesh, float *nodes, int32_t *n_nodes, int32_t *order, int32_t *n_tris) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (!ctx->uploaded) return fail(ctx, RT_ERR_STATE, "no scene uploaded");
+    if (mesh < 0 || mesh >= ctx->n_meshes) return fail(ctx, RT_ERR_INVALID, "mesh index out of range");
+    RT_HIP(hipSetDevice(ctx->device));
+    RT_HIP(hipStreamSynchronize(ctx->stream));
+    const DevMesh &m = ctx->meshes[mesh];
+    int nn = ctx->built ? std::max(m.tri_count - 1, 0) : 0;
+    if (n_nodes) *n_nodes = nn;
+    if (n_tris) *n_tris = m.tri_count;
+    if (nodes && nn) RT_HIP(hipMemcpy(nodes, ctx->d_nodes + m.node_offset, (size_t)nn * sizeof(BvhNode), hipMemcpyDeviceToHost));
+    if (order && m.tri_count) RT_HIP(hipMemcpy(order, ctx->d_tri_orig + m.tri_offset, (size_t)m.tri_count * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return RT_OK;
+}

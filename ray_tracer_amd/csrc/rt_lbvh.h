@@ -1,0 +1,128 @@
+// rt_lbvh.h -- per-element steps of the Morton-code LBVH build (Karras 2012 radix tree over
+// unique 64-bit keys, then a bottom-up fit).  The reference has no acceleration structure beyond
+// the per-mesh Box gate: Mesh::intersect scans every fragment (main.cpp:534-539).  The tree only
+// decides WHICH triangles are tested; the triangle test itself and the tie-break order are those
+// of the reference, so closest-hit results are identical to the linear scan.
+//
+// Each function handles one element (triangle / node) and is called by the HIP kernels in
+// rt_device.hip, one thread per element.  Host-compilable for the CPU logic tests.
+#pragma once
+
+#include "rt_core.h"
+
+namespace rtc {
+
+// spreads the low 10 bits of v to every third bit
+RT_HD uint32_t expand_bits10(uint32_t v) {
+    v = (v * 0x00010001u) & 0xFF0000FFu;
+    v = (v * 0x00000101u) & 0x0F00F00Fu;
+    v = (v * 0x00000011u) & 0xC30C30C3u;
+    v = (v * 0x00000005u) & 0x49249249u;
+    return v;
+}
+RT_HD uint32_t morton30(float x, float y, float z) {  // x, y, z in [0, 1]
+    float fx = fminf(fmaxf(x * 1024.0f, 0.0f), 1023.0f);
+    float fy = fminf(fmaxf(y * 1024.0f, 0.0f), 1023.0f);
+    float fz = fminf(fmaxf(z * 1024.0f, 0.0f), 1023.0f);
+    return expand_bits10((uint32_t)fx) * 4u + expand_bits10((uint32_t)fy) * 2u + expand_bits10((uint32_t)fz);
+}
+
+// Sort key of triangle i of a mesh: Morton code of the centroid inside the mesh bounds in the high
+// word, the triangle index in the low word (keys are unique, so the radix tree is well defined and
+// the build is deterministic).  Non-finite coordinates sort last.
+RT_HD uint64_t tri_sort_key(const float *p, const float *lo, const float *hi, uint32_t i) {
+    float c[3];
+    for (int a = 0; a < 3; a++) {
+        float ctr = (p[a] + p[3 + a] + p[6 + a]) * (1.0f / 3.0f);
+        float ext = hi[a] - lo[a];
+        float u = ext > 0 ? (ctr - lo[a]) / ext : 0.5f;
+        c[a] = (u == u) ? u : 1.0f;
+    }
+    return ((uint64_t)morton30(c[0], c[1], c[2]) << 32) | (uint64_t)i;
+}
+
+// Triangle record used by the intersection test: p1 p2 p3 and sn = cross(p2-p1, p3-p1)
+// (main.cpp:377) as three 16-byte words.
+RT_HD void make_tri_test(const float *p, f4 *out) {
+    v3 p1 = ld3(p), p2 = ld3(p + 3), p3 = ld3(p + 6);
+    v3 sn = cross(p2 - p1, p3 - p1);
+    out[0].x = p1.x; out[0].y = p1.y; out[0].z = p1.z; out[0].w = p2.x;
+    out[1].x = p2.y; out[1].y = p2.z; out[1].z = p3.x; out[1].w = p3.y;
+    out[2].x = p3.z; out[2].y = sn.x; out[2].z = sn.y; out[2].w = sn.z;
+}
+
+RT_HD int clz64(uint64_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __clzll((long long)x);
+#else
+    return x ? __builtin_clzll(x) : 64;
+#endif
+}
+// length of the common prefix of keys i and j, -1 outside the array
+RT_HD int lbvh_delta(const uint64_t *keys, int n, int i, int j) {
+    if (j < 0 || j >= n) return -1;
+    return clz64(keys[i] ^ keys[j]);
+}
+
+// Internal node i (0 <= i < n-1) of the radix tree over n sorted keys: its two children, encoded
+// like BvhNode::c0/c1 (>= 0 internal node, < 0 leaf ~position).
+RT_HD void lbvh_node_children(const uint64_t *keys, int n, int i, int32_t &c0, int32_t &c1) {
+    int d = (lbvh_delta(keys, n, i, i + 1) - lbvh_delta(keys, n, i, i - 1)) >= 0 ? 1 : -1;
+    int dmin = lbvh_delta(keys, n, i, i - d);
+    int lmax = 2;
+    while (lbvh_delta(keys, n, i, i + lmax * d) > dmin) lmax *= 2;
+    int l = 0;
+    for (int t = lmax / 2; t >= 1; t /= 2)
+        if (lbvh_delta(keys, n, i, i + (l + t) * d) > dmin) l += t;
+    int j = i + l * d;
+    int dnode = lbvh_delta(keys, n, i, j);
+    int s = 0, t = l;
+    do {
+        t = (t + 1) >> 1;
+        if (lbvh_delta(keys, n, i, i + (s + t) * d) > dnode) s += t;
+    } while (t > 1);
+    int gamma = i + s * d + (d < 0 ? d : 0);
+    int first = i < j ? i : j, last = i < j ? j : i;
+    c0 = (first == gamma) ? ~gamma : gamma;
+    c1 = (last == gamma + 1) ? ~(gamma + 1) : gamma + 1;
+}
+
+// Bounds of a sorted triangle, grown by `pad` on every side so that the slab test never rejects a
+// ray the exact triangle test accepts.
+RT_HD void tri_bounds(const f4 *tt, int k, float pad, float *lo, float *hi) {
+    f4 A = tt[3 * k], B = tt[3 * k + 1], C = tt[3 * k + 2];
+    float px[3] = {A.x, A.w, B.z}, py[3] = {A.y, B.x, B.w}, pz[3] = {A.z, B.y, C.x};
+    lo[0] = fminf(px[0], fminf(px[1], px[2])) - pad; hi[0] = fmaxf(px[0], fmaxf(px[1], px[2])) + pad;
+    lo[1] = fminf(py[0], fminf(py[1], py[2])) - pad; hi[1] = fmaxf(py[0], fmaxf(py[1], py[2])) + pad;
+    lo[2] = fminf(pz[0], fminf(pz[1], pz[2])) - pad; hi[2] = fmaxf(pz[0], fmaxf(pz[1], pz[2])) + pad;
+}
+
+// One fitting pass over internal node i.  done_pass[i] is 0 until the node is completed and then
+// holds the number of the pass that completed it.  A node may be completed in pass `pass` once each
+// child is a leaf or was completed in an EARLIER pass (so its bounds are already in memory).
+// Returns 0: was already done, 1: completed now, 2: still waiting.
+RT_HD int lbvh_fit_node(int i, int pass, const int32_t *c0s, const int32_t *c1s, const f4 *tt, float pad,
+                        int32_t *done_pass, float *node_lo, float *node_hi, int32_t *height, BvhNode *nodes) {
+    if (done_pass[i]) return 0;
+    int32_t c0 = c0s[i], c1 = c1s[i];
+    int d0 = c0 < 0 ? 0 : done_pass[c0], d1 = c1 < 0 ? 0 : done_pass[c1];
+    bool r0 = c0 < 0 || (d0 != 0 && d0 < pass), r1 = c1 < 0 || (d1 != 0 && d1 < pass);
+    if (!(r0 && r1)) return 2;
+    BvhNode nd;
+    int h0 = 0, h1 = 0;
+    if (c0 < 0) tri_bounds(tt, ~c0, pad, nd.lo0, nd.hi0);
+    else { for (int a = 0; a < 3; a++) { nd.lo0[a] = node_lo[3 * c0 + a]; nd.hi0[a] = node_hi[3 * c0 + a]; } h0 = height[c0]; }
+    if (c1 < 0) tri_bounds(tt, ~c1, pad, nd.lo1, nd.hi1);
+    else { for (int a = 0; a < 3; a++) { nd.lo1[a] = node_lo[3 * c1 + a]; nd.hi1[a] = node_hi[3 * c1 + a]; } h1 = height[c1]; }
+    nd.c0 = c0; nd.c1 = c1; nd.pad0 = 0; nd.pad1 = 0;
+    for (int a = 0; a < 3; a++) {
+        node_lo[3 * i + a] = fminf(nd.lo0[a], nd.lo1[a]);
+        node_hi[3 * i + a] = fmaxf(nd.hi0[a], nd.hi1[a]);
+    }
+    height[i] = 1 + (h0 > h1 ? h0 : h1);
+    nodes[i] = nd;
+    done_pass[i] = pass;
+    return 1;
+}
+
+}  // namespace rtc

@@ -1,0 +1,211 @@
+// twin.cpp -- TEST SCAFFOLDING ONLY.  Compiles the renderer's per-ray code (rt_core.h), LBVH build
+// steps (rt_lbvh.h) and scene preparation (rt_prepare.h) as host C++ and drives them serially, so
+// that the logic the HIP kernels execute can be checked against the oracle on a machine without a
+// GPU.  The kernels' thread-per-element loops become plain loops here.  Nothing in the shipped
+// libraries links this file; it is built by tests/conftest.py into tests/cpu_twin/.
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "rt_amd.h"
+#include "rt_core.h"
+#include "rt_lbvh.h"
+#include "rt_prepare.h"
+
+using namespace rtc;
+
+namespace {
+
+struct VecStack {
+    int32_t data[kStackDepth];
+    int sp = 0;
+    int max_sp = 0;
+    void reset() { sp = 0; }
+    bool empty() const { return sp == 0; }
+    void push(int32_t v) { if (sp < kStackDepth) { data[sp++] = v; if (sp > max_sp) max_sp = sp; } }
+    int32_t pop() { return data[--sp]; }
+};
+
+struct Twin {
+    std::string err;
+    DevScene S{};
+    std::vector<rt_object> objects;
+    std::vector<rt_sphere> spheres;
+    std::vector<rt_plane> planes;
+    std::vector<rt_cone> cones;
+    std::vector<DevMesh> meshes;
+    std::vector<MeshBuild> build;
+    std::vector<f4> tri_test, gate;
+    std::vector<uint32_t> tri_key;
+    std::vector<int32_t> tri_orig, tri_material, tri_frag, tri_sub;
+    std::vector<float> tri_pos, tri_nrm, tri_uv, light_pos, light_color;
+    std::vector<BvhNode> nodes;
+    std::vector<rt_material> materials;
+    std::vector<DevTexture> textures;
+    std::vector<std::vector<uint8_t>> maps;
+    int bvh_max_depth = 0;
+    Work total{};
+};
+
+void gather(Twin &t, const DevMesh &m, const std::vector<uint64_t> *keys) {
+    for (int k = 0; k < m.tri_count; k++) {
+        int local = keys ? (int)(uint32_t)((*keys)[k] & 0xffffffffull) : k;
+        int orig = m.tri_offset + local;
+        make_tri_test(&t.tri_pos[9 * (size_t)orig], &t.tri_test[3 * (size_t)(m.tri_offset + k)]);
+        t.tri_key[m.tri_offset + k] = 2u * (uint32_t)t.tri_frag[orig] + (1u - (uint32_t)t.tri_sub[orig]);
+        t.tri_orig[m.tri_offset + k] = orig;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+void *twin_create(const rt_scene_desc *sc, char *errbuf, int errcap) {
+    std::string bad = validate_scene(sc);
+    if (!bad.empty()) {
+        if (errbuf && errcap > 0) { std::strncpy(errbuf, bad.c_str(), errcap - 1); errbuf[errcap - 1] = 0; }
+        return nullptr;
+    }
+    Twin *t = new Twin();
+    t->objects.assign(sc->objects, sc->objects + sc->n_objects);
+    t->spheres.assign(sc->spheres, sc->spheres + sc->n_spheres);
+    t->planes.assign(sc->planes, sc->planes + sc->n_planes);
+    t->cones.assign(sc->cones, sc->cones + sc->n_cones);
+    size_t nt = sc->n_triangles;
+    t->tri_pos.assign(sc->tri_pos, sc->tri_pos + 9 * nt);
+    t->tri_nrm.assign(sc->tri_nrm, sc->tri_nrm + 9 * nt);
+    t->tri_uv.assign(sc->tri_uv, sc->tri_uv + 6 * nt);
+    t->tri_material.assign(sc->tri_material, sc->tri_material + nt);
+    t->tri_frag.assign(sc->tri_frag, sc->tri_frag + nt);
+    t->tri_sub.assign(sc->tri_sub, sc->tri_sub + nt);
+    t->materials.assign(sc->materials, sc->materials + sc->n_materials);
+    t->light_pos.assign(sc->light_pos, sc->light_pos + 3 * (size_t)sc->n_lights);
+    t->light_color.assign(sc->light_color, sc->light_color + 3 * (size_t)sc->n_lights);
+    t->textures.resize(sc->n_textures);
+    for (int i = 0; i < sc->n_textures; i++) {
+        const rt_texture &x = sc->textures[i];
+        DevTexture &d = t->textures[i];
+        d.kind = x.kind; d.w = x.width; d.h = x.height; d.pad = 0;
+        const uint8_t *src[4] = {x.base_color, x.normal, x.occlusion, x.roughness};
+        for (int k = 0; k < 4; k++) {
+            d.maps[k] = nullptr;
+            if (x.kind == RT_TEX_IMAGE) {
+                t->maps.emplace_back(src[k], src[k] + (size_t)x.width * x.height * 4);
+                d.maps[k] = t->maps.back().data();
+            }
+        }
+    }
+    int node_total = prepare_meshes(sc, t->meshes, t->build, t->gate);
+    t->tri_test.assign(3 * nt, f4{0, 0, 0, 0});
+    t->tri_key.assign(nt, 0);
+    t->tri_orig.assign(nt, 0);
+    t->nodes.assign(std::max(node_total, 1), BvhNode{});
+    for (const DevMesh &m : t->meshes) gather(*t, m, nullptr);
+    DevScene &S = t->S;
+    S.n_objects = sc->n_objects; S.n_lights = sc->n_lights;
+    S.objects = t->objects.data(); S.spheres = t->spheres.data(); S.planes = t->planes.data(); S.cones = t->cones.data();
+    S.meshes = t->meshes.data(); S.tri_test = t->tri_test.data(); S.tri_key = t->tri_key.data(); S.tri_orig = t->tri_orig.data();
+    S.tri_nrm = t->tri_nrm.data(); S.tri_uv = t->tri_uv.data(); S.tri_material = t->tri_material.data();
+    S.tri_frag = t->tri_frag.data(); S.tri_sub = t->tri_sub.data(); S.gate_tri = t->gate.data(); S.nodes = t->nodes.data();
+    S.materials = t->materials.data(); S.textures = t->textures.data();
+    S.light_pos = t->light_pos.data(); S.light_color = t->light_color.data();
+    for (int a = 0; a < 3; a++) S.ambient[a] = sc->ambient[a];
+    return t;
+}
+
+void twin_destroy(void *h) { delete static_cast<Twin *>(h); }
+
+// the LBVH build of rt_build_accel, one mesh after the other; returns the maximum tree height
+int twin_build_accel(void *h) {
+    Twin *t = static_cast<Twin *>(h);
+    t->bvh_max_depth = 0;
+    for (size_t mi = 0; mi < t->meshes.size(); mi++) {
+        const DevMesh &m = t->meshes[mi];
+        int n = m.tri_count;
+        if (n <= 0) continue;
+        std::vector<uint64_t> keys(n);
+        for (int i = 0; i < n; i++) keys[i] = tri_sort_key(&t->tri_pos[9 * (size_t)(m.tri_offset + i)], t->build[mi].lo, t->build[mi].hi, (uint32_t)i);
+        std::sort(keys.begin(), keys.end());
+        gather(*t, m, &keys);
+        if (n < 2) continue;
+        std::vector<int32_t> c0(n - 1), c1(n - 1), done(n - 1, 0), height(n - 1, 0);
+        std::vector<float> lo(3 * (size_t)(n - 1)), hi(3 * (size_t)(n - 1));
+        for (int i = 0; i < n - 1; i++) lbvh_node_children(keys.data(), n, i, c0[i], c1[i]);
+        const f4 *tt = &t->tri_test[3 * (size_t)m.tri_offset];
+        for (int pass = 1; pass <= 4096; pass++) {
+            int left = 0;
+            for (int i = 0; i < n - 1; i++)
+                if (lbvh_fit_node(i, pass, c0.data(), c1.data(), tt, t->build[mi].pad, done.data(), lo.data(), hi.data(), height.data(),
+                                  &t->nodes[m.node_offset]) == 2)
+                    left++;
+            if (!left) break;
+        }
+        t->build[mi].height = height[0];
+        t->bvh_max_depth = std::max(t->bvh_max_depth, height[0]);
+    }
+    return t->bvh_max_depth;
+}
+
+void twin_trace_rays(void *h, int64_t n, const float *o, const float *d, int max_depth, int accel, rt_hit_record *hits,
+                     float *radiance, int *max_stack) {
+    Twin *t = static_cast<Twin *>(h);
+    int ms = 0;
+#pragma omp parallel for schedule(dynamic, 64) reduction(max : ms)
+    for (int64_t r = 0; r < n; r++) {
+        VecStack stk;
+        Work wk;
+        work_zero(wk);
+        rt_hit_record hr;
+        v3 c = trace<false>(t->S, ld3(o + 3 * r), ld3(d + 3 * r), max_depth, accel, stk, wk, hits ? &hr : nullptr);
+        if (hits) hits[r] = hr;
+        if (radiance) { radiance[3 * r] = c.x; radiance[3 * r + 1] = c.y; radiance[3 * r + 2] = c.z; }
+        ms = std::max(ms, stk.max_sp);
+    }
+    if (max_stack) *max_stack = ms;
+}
+
+void twin_intersect_object(void *h, int object, int64_t n, const float *o, const float *d, int accel, rt_hit_record *hits) {
+    Twin *t = static_cast<Twin *>(h);
+#pragma omp parallel for schedule(dynamic, 64)
+    for (int64_t r = 0; r < n; r++) {
+        VecStack stk;
+        Work wk;
+        work_zero(wk);
+        intersect_object<false>(t->S, object, ld3(o + 3 * r), ld3(d + 3 * r), accel, hits[r], stk, wk);
+    }
+}
+
+// the pixel loop of k_render over [x0,x1) x [y0,y1); counters[10] accumulates the Work fields
+void twin_render(void *h, const rt_render_params *p, int x0, int y0, int x1, int y1, float *rgb, uint8_t *rgb8,
+                 unsigned long long *counters) {
+    Twin *t = static_cast<Twin *>(h);
+    Camera cam = make_camera(p->width, p->height, p->fov);
+    unsigned long long acc[10] = {0};
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : acc[:10])
+    for (int j = y0; j < y1; j++)
+        for (int i = x0; i < x1; i++) {
+            VecStack stk;
+            Work wk;
+            work_zero(wk);
+            v3 c = render_pixel<true>(t->S, cam, p->mode, p->grid_m, p->max_depth, p->accel, i, j, stk, wk);
+            size_t q = 3 * ((size_t)j * p->width + i);
+            if (rgb) { rgb[q] = c.x; rgb[q + 1] = c.y; rgb[q + 2] = c.z; }
+            if (rgb8) { v3 tm = tone_map(c); rgb8[q] = quantise(tm.x); rgb8[q + 1] = quantise(tm.y); rgb8[q + 2] = quantise(tm.z); }
+            uint32_t vals[10] = {wk.rays_primary, wk.rays_shadow, wk.rays_secondary, wk.tri, wk.box, wk.gate, wk.quadric, wk.plane, wk.shade, wk.tex};
+            for (int k = 0; k < 10; k++) acc[k] += vals[k];
+        }
+    if (counters) for (int k = 0; k < 10; k++) counters[k] += acc[k];
+}
+
+int twin_copy_bvh(void *h, int mesh, float *nodes, int32_t *order) {
+    Twin *t = static_cast<Twin *>(h);
+    const DevMesh &m = t->meshes[mesh];
+    int nn = std::max(m.tri_count - 1, 0);
+    if (nodes && nn) std::memcpy(nodes, &t->nodes[m.node_offset], (size_t)nn * sizeof(BvhNode));
+    if (order) std::memcpy(order, &t->tri_orig[m.tri_offset], (size_t)m.tri_count * sizeof(int32_t));
+    return nn;
+}
+}
