@@ -1018,6 +1018,11 @@ static v3 refract_dir(v3 i, v3 n, float index) {
     return add3(scl3(a, alpha), scl3(b, beta));
 }
 
+void orc_refract(const float *i, const float *n, float index, float *out) {
+    v3 r = refract_dir(V3(i[0], i[1], i[2]), V3(n[0], n[1], n[2]), index);
+    out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
+
 static inline float clamp01(float x) { /* glm::clamp = min(max(x, 0), 1) */
     float m = (x < 0.0f) ? 0.0f : x;
     return (1.0f < m) ? 1.0f : m;

@@ -106,6 +106,8 @@ void orc_find_closest_hit(const orc_scene *s, int n, const float *o, const float
  * receives the number of find_closest_hit evaluations per input ray. */
 void orc_trace_rays(const orc_scene *s, int n, const float *o, const float *d, int max_depth,
                     float *radiance, uint64_t *rays_out);
+/* refract (main.cpp:627-633) on one incident direction */
+void orc_refract(const float *i, const float *n, float index, float *out);
 /* texture samplers (Textures.cpp:9-55): which = 0 texture(), 1 normal(), 2 occlusion(), 3 roughness() */
 void orc_sample_texture(const orc_scene *s, int tex, int which, int n, const float *uv, float *out3);
 

@@ -1,0 +1,123 @@
+"""Shared parity checks: a backend (CPU twin or GPU context) against the CPU oracle.
+
+Bars (the reference's own numerics are the target):
+  * hit object / fragment / sub-triangle ids exact, except grazing-edge ties: rays that pass through
+    an edge or vertex shared by several triangles, where both sides report the same distance and
+    the reference's winner is decided by the last bit of a cross product;
+  * and except spurious far hits: for a ray almost parallel to a triangle's plane the reference's
+    test (main.cpp:377-395) can accept a point millions of triangle sizes away, where its three
+    cross products are pure cancellation noise (typically with a NaN normal).  Such a "hit" lies far
+    outside the triangle's bounds, so the LBVH never visits it; it can only matter when nothing else
+    is hit.  is_spurious_far_hit() defines the class;
+  * distance, normal, uv, point of matching hits to 1e-5 relative / 1e-4 absolute;
+  * radiance within 1e-4 relative (floor 1e-6 absolute) on >= 99.9 % of the rays;
+  * 8-bit output within +-1 LSB on >= 99.9 % of the pixels.
+"""
+import numpy as np
+
+RADIANCE_RTOL = 1e-4
+RADIANCE_FLOOR = 1e-6
+MAX_TIE_FRACTION = 2e-3
+
+
+def mesh_world_targets(desc, rng, per_mesh=300):
+    """World-space vertices, edge midpoints and centroids of a sample of each mesh's triangles,
+    from a flattened scene description (rays aimed exactly at them graze shared edges)."""
+    out = []
+    if desc.n_triangles == 0:
+        return np.zeros((0, 3), np.float32)
+    pos_all = np.ctypeslib.as_array(desc.tri_pos, shape=(max(desc.n_triangles, 1) * 9,)).reshape(-1, 3, 3)
+    for mi in range(desc.n_meshes):
+        m = desc.meshes[mi]
+        if m.tri_count == 0:
+            continue
+        idx = m.tri_offset + rng.choice(m.tri_count, size=min(m.tri_count, per_mesh), replace=False)
+        p = pos_all[idx].astype(np.float32)
+        local = np.concatenate([p[:, 0], p[:, 1], 0.5 * (p[:, 0] + p[:, 1]), 0.5 * (p[:, 1] + p[:, 2]), p.mean(1)])
+        M = np.array(m.to_world[:], np.float32).reshape(4, 3)  # four columns of three rows
+        out.append(local @ M[:3] + M[3])
+    return np.concatenate(out).astype(np.float32) if out else np.zeros((0, 3), np.float32)
+
+
+def ray_set(osc, desc=None, w=96, h=72, seed=0, n_random=1500):
+    """Primary rays of a small frame, rays leaving the hit points (towards a light, mirrored,
+    straight on), random rays, and rays aimed exactly at mesh vertices / edge midpoints from the
+    camera and from a light position."""
+    import oracle_lib as O
+    rng = np.random.default_rng(seed)
+    o, d, _ = O.camera_rays(w, h)
+    hits = osc.find_closest_hit(o, d)
+    ok = hits["hit"] == 1
+    pts, nrm = hits["point"][ok], hits["normal"][ok]
+    light = np.array([10, 16, -7], np.float32)
+    l = light - pts
+    l /= np.linalg.norm(l, axis=1, keepdims=True)
+    din = d[ok] / np.linalg.norm(d[ok], axis=1, keepdims=True)
+    refl = din - 2 * (din * nrm).sum(1, keepdims=True) * nrm
+    sel = rng.choice(len(pts), size=min(len(pts), 2000), replace=False)
+    so = np.concatenate([pts[sel] + 1e-4 * l[sel], pts[sel] + 1e-4 * refl[sel], pts[sel] + 1e-4 * din[sel]])
+    sd = np.concatenate([l[sel], refl[sel], din[sel]])
+    ro = rng.uniform(-8, 8, size=(n_random, 3)).astype(np.float32) * np.array([1, 0.6, 1], np.float32) + np.array([0, 2, 8], np.float32)
+    rd = rng.normal(size=(n_random, 3)).astype(np.float32)
+    os_, ds_ = [o, so, ro], [d, sd, rd]
+    if desc is not None:
+        t = mesh_world_targets(desc, rng)
+        if len(t):
+            os_ += [np.zeros_like(t), np.tile(light, (len(t), 1))]
+            ds_ += [t, t - light]
+    return np.concatenate(os_).astype(np.float32), np.concatenate(ds_).astype(np.float32)
+
+
+FAR_HIT_DISTANCE = 1e5  # far beyond any scene here (rooms are ~50 units)
+
+
+def is_spurious_far_hit(r):
+    return r["hit"] == 1 and (not np.all(np.isfinite(r["normal"])) or not np.isfinite(r["distance"]) or r["distance"] > FAR_HIT_DISTANCE)
+
+
+def check_hits(ref, got, what=""):
+    assert len(ref) == len(got)
+    same = (ref["hit"] == got["hit"]) & (ref["object"] == got["object"]) & (ref["frag"] == got["frag"]) & (ref["sub"] == got["sub"])
+    bad = np.flatnonzero(~same)
+    ties = 0
+    for i in bad:
+        r, g = ref[i], got[i]
+        # a tie: both hit the same object at (nearly) the same distance but report different triangles
+        if r["hit"] == 1 and g["hit"] == 1 and r["object"] == g["object"] and abs(r["distance"] - g["distance"]) <= 1e-5 * max(1.0, abs(r["distance"])):
+            ties += 1
+        elif is_spurious_far_hit(r) and (g["hit"] == 0 or is_spurious_far_hit(g)):
+            ties += 1
+        else:
+            raise AssertionError(f"{what}: ray {i} differs beyond a grazing tie:\n ref {r}\n got {g}")
+    assert ties <= MAX_TIE_FRACTION * len(ref), f"{what}: {ties} grazing ties in {len(ref)} rays"
+    m = same & (ref["hit"] == 1)
+    if m.any():
+        np.testing.assert_allclose(got["distance"][m], ref["distance"][m], rtol=1e-5, atol=1e-5, err_msg=what)
+        np.testing.assert_allclose(got["normal"][m], ref["normal"][m], atol=1e-4, err_msg=what)
+        np.testing.assert_allclose(got["point"][m], ref["point"][m], rtol=1e-5, atol=1e-4, err_msg=what)
+        np.testing.assert_allclose(got["uv"][m], ref["uv"][m], rtol=1e-4, atol=1e-4, err_msg=what)
+        assert np.array_equal(got["from_outside"][m], ref["from_outside"][m]), what
+    return ties
+
+
+def radiance_error(ref, got):
+    ref, got = np.asarray(ref, np.float64), np.asarray(got, np.float64)
+    both_nan = np.isnan(ref) & np.isnan(got)
+    err = np.abs(ref - got) / np.maximum(np.abs(ref), RADIANCE_FLOOR)
+    err[both_nan] = 0
+    err[np.isnan(err)] = np.inf
+    return err.reshape(len(err), -1).max(axis=1) if err.ndim > 1 else err
+
+
+def check_radiance(ref, got, what="", frac=0.999):
+    err = radiance_error(np.asarray(ref).reshape(-1, 3), np.asarray(got).reshape(-1, 3))
+    ok = (err <= RADIANCE_RTOL).mean()
+    assert ok >= frac, f"{what}: only {ok:.5f} of the rays within {RADIANCE_RTOL} relative (worst {err.max():.3g})"
+    return err
+
+
+def check_rgb8(ref, got, what="", frac=0.999):
+    diff = np.abs(ref.astype(np.int32) - got.astype(np.int32)).reshape(-1, 3).max(axis=1)
+    ok = (diff <= 1).mean()
+    assert ok >= frac, f"{what}: only {ok:.5f} of the pixels within 1 LSB (worst {diff.max()})"
+    return diff

@@ -1,0 +1,228 @@
+"""Parity tests proper: the HIP kernels, called through the C ABI (ray_tracer_amd.Context forwards to
+librt_amd.so), against the CPU oracle and the committed golden vectors.  Bars: tests/parity.py."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import parity
+import ray_tracer_amd as rt
+from ray_tracer_amd import tiling
+
+pytestmark = pytest.mark.gpu
+PRESETS = ["analytic", "teapot", "teapot_head", "shells", "textured"]
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_native_library_is_what_runs(gpu_ctx):
+    """The HIP extension must be the code that executes: it is loaded from the tree and a context exists."""
+    gpu_ctx("analytic")
+    maps = open("/proc/self/maps").read()
+    assert os.path.join(rt.ROOT, "ray_tracer_amd", "librt_amd.so") in maps
+
+
+@pytest.mark.parametrize("preset", PRESETS)
+@pytest.mark.parametrize("accel", [rt.ACCEL_LBVH, rt.ACCEL_BRUTE])
+def test_golden_rays(preset, accel, gpu_ctx):
+    g = np.load(os.path.join(GOLDEN, preset + ".npz"))
+    hits, rad = gpu_ctx(preset).trace_rays(g["o"], g["d"], max_depth=int(g["max_depth"]), accel=accel)
+    parity.check_hits(g["hits"], hits, f"{preset}/accel{accel}")
+    parity.check_radiance(g["radiance"], rad, f"{preset}/accel{accel}")
+
+
+@pytest.mark.parametrize("preset", PRESETS)
+def test_golden_frames(preset, gpu_ctx):
+    g = np.load(os.path.join(GOLDEN, preset + ".npz"))
+    for mode, key in ((rt.MODE_REF_1SPP, "frame_1spp"), (rt.MODE_REF_AA9, "frame_aa9")):
+        rgb, rgb8 = gpu_ctx(preset).render(64, 48, mode=mode, max_depth=int(g["max_depth"]))
+        parity.check_radiance(g[key], rgb, f"{preset}/{key}")
+        parity.check_rgb8(g[key + "_rgb8"], rgb8, f"{preset}/{key}")
+
+
+@pytest.mark.parametrize("preset", PRESETS)
+def test_live_oracle_rays(preset, gpu_ctx, oracle_scene, host_scene):
+    """A different, seeded ray set checked against the oracle computed here."""
+    osc = oracle_scene(preset)
+    o, d = parity.ray_set(osc, host_scene(preset).flatten().contents, w=80, h=60, seed=5, n_random=1000)
+    ref_hits = osc.find_closest_hit(o, d)
+    ref_rad, ref_rays = osc.trace_rays(o, d, 8)
+    ctx = gpu_ctx(preset)
+    ctx.reset_counters()
+    hits, rad = ctx.trace_rays(o, d, max_depth=8)
+    parity.check_hits(ref_hits, hits, preset)
+    parity.check_radiance(ref_rad, rad, preset)
+    # ray accounting: one ray per closest-hit query, as the oracle counts them (ties may shift a few)
+    assert abs(int(ctx.counters().rays) - int(ref_rays.sum())) <= 2e-3 * int(ref_rays.sum())
+
+
+@pytest.mark.parametrize("preset", ["analytic", "teapot", "shells"])
+def test_per_object_intersect(preset, gpu_ctx, oracle_scene, host_scene):
+    osc = oracle_scene(preset)
+    o, d = parity.ray_set(osc, host_scene(preset).flatten().contents, w=48, h=36, seed=6, n_random=500)
+    for obj in range(osc.num_objects):
+        ref = osc.intersect_object(obj, o, d)
+        got = gpu_ctx(preset).intersect_object(obj, o, d)
+        parity.check_hits(ref, got, f"{preset}/object{obj}")
+
+
+@pytest.mark.parametrize("preset,mode,grid,size", [("analytic", rt.MODE_REF_AA9, 1, (160, 90)), ("teapot", rt.MODE_GRID, 4, (160, 90)),
+                                                   ("shells", rt.MODE_GRID, 2, (96, 54)), ("textured", rt.MODE_GRID, 3, (128, 128)),
+                                                   ("teapot", rt.MODE_REF_1SPP, 1, (250, 130))])
+def test_frames_against_live_oracle(preset, mode, grid, size, gpu_ctx, oracle_scene):
+    w, h = size  # includes sizes that are not multiples of the 16-pixel tile
+    ref_rgb, ref_rgb8, ref_rays = oracle_scene(preset).render(w, h, mode=mode, grid_m=grid, max_depth=8)
+    ctx = gpu_ctx(preset)
+    ctx.reset_counters()
+    rgb, rgb8 = ctx.render(w, h, mode=mode, grid_m=grid, max_depth=8)
+    parity.check_radiance(ref_rgb, rgb, preset)
+    parity.check_rgb8(ref_rgb8, rgb8, preset)
+    assert abs(int(ctx.counters().rays) - ref_rays) <= 2e-3 * ref_rays
+
+
+def test_lbvh_equals_brute_force_on_gpu(gpu_ctx):
+    """Identical images from the LBVH and from the reference-order linear scan (bitwise: the tree only
+    chooses which triangles are tested)."""
+    for preset in ("teapot", "shells"):
+        ctx = gpu_ctx(preset)
+        a, a8 = ctx.render(192, 108, mode=rt.MODE_REF_1SPP, accel=rt.ACCEL_LBVH)
+        b, b8 = ctx.render(192, 108, mode=rt.MODE_REF_1SPP, accel=rt.ACCEL_BRUTE)
+        assert np.array_equal(a8, b8)
+        assert np.array_equal(a, b, equal_nan=True)
+
+
+def test_lbvh_structure_on_gpu(gpu_ctx, host_scene):
+    for preset in ("teapot", "shells"):
+        d = host_scene(preset).flatten().contents
+        ctx = gpu_ctx(preset)
+        pos_all = np.ctypeslib.as_array(d.tri_pos, shape=(d.n_triangles * 9,)).reshape(-1, 3, 3)
+        for mi in range(d.n_meshes):
+            m = d.meshes[mi]
+            nodes, order = ctx.copy_bvh(mi)
+            assert len(nodes) == m.tri_count - 1
+            assert sorted(order) == list(range(m.tri_offset, m.tri_offset + m.tri_count))
+            ch = nodes[:, 12:14].copy().view(np.int32)
+            leaves = np.concatenate([~ch[ch < 0]])
+            assert sorted(leaves) == list(range(m.tri_count))
+            internal = ch[ch >= 0]
+            assert sorted(internal) == list(range(1, len(nodes)))
+            # leaf boxes enclose their triangle
+            for c in range(0, len(nodes), 97):
+                for side in (0, 1):
+                    k = ch[c, side]
+                    if k < 0:
+                        p = pos_all[order[~k]]
+                        lo, hi = nodes[c, 6 * side:6 * side + 3], nodes[c, 6 * side + 3:6 * side + 6]
+                        assert np.all(lo <= p.min(0)) and np.all(hi >= p.max(0))
+        assert 0 < ctx.counters().bvh_max_depth <= 40
+
+
+def test_cpu_twin_and_gpu_agree_on_the_lbvh(gpu_ctx, host_scene):
+    """The serial host build and the GPU build produce the same tree (same keys, same sort, same fit)."""
+    import twin_lib as T
+    d = host_scene("teapot").flatten().contents
+    tw = T.Twin(host_scene("teapot"))
+    n0, o0 = tw.copy_bvh(0, d.meshes[0].tri_count)
+    n1, o1 = gpu_ctx("teapot").copy_bvh(0)
+    assert np.array_equal(o0, o1)
+    assert np.array_equal(n0.view(np.uint32), n1.view(np.uint32))
+
+
+def test_sharded_render_reassembles_bitwise(gpu_ctx):
+    """Tile sharding as used across GPUs: every rank's shard rendered on this GPU, gathered in rank-major
+    order and de-interleaved by rt_untile_device, equals the single-rank frame bit for bit."""
+    import torch
+    ctx = gpu_ctx("teapot")
+    w, h = 200, 120  # 13 x 8 tiles: not divisible by the world sizes below
+    full, full8 = ctx.render(w, h, mode=rt.MODE_GRID, grid_m=2)
+    for world in (2, 3, 8):
+        p0 = ctx.params(w, h, mode=rt.MODE_GRID, grid_m=2, world_size=world)
+        per, total = ctx.shard_tiles(p0)
+        assert total == 13 * 8 and per == -(-total // world)
+        shards = torch.zeros((world, per, 16, 16, 3), dtype=torch.float32, device="cuda")
+        shards8 = torch.zeros((world, per, 16, 16, 3), dtype=torch.uint8, device="cuda")
+        for r in range(world):
+            p = ctx.params(w, h, mode=rt.MODE_GRID, grid_m=2, rank=r, world_size=world)
+            ctx.render_shard_device(p, shards[r].data_ptr(), shards8[r].data_ptr())
+        frame = torch.zeros((h, w, 3), dtype=torch.float32, device="cuda")
+        frame8 = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda")
+        ctx.untile_device(p0, shards.data_ptr(), frame.data_ptr(), shards8.data_ptr(), frame8.data_ptr())
+        ctx.sync()
+        assert np.array_equal(frame.cpu().numpy(), full, equal_nan=True)
+        assert np.array_equal(frame8.cpu().numpy(), full8)
+        # the host-side restatement of the tile rule agrees with the kernels
+        assert np.array_equal(tiling.frame_from_shards(shards.cpu().numpy(), w, h), full, equal_nan=True)
+        # rt_render with world_size > 1 writes only this rank's tiles
+        part, _ = ctx.render(w, h, mode=rt.MODE_GRID, grid_m=2, rank=1, world_size=world)
+        mine = tiling.frame_from_shards(np.stack([tiling.shard_from_frame(full, r, world) * (r == 1) for r in range(world)]), w, h)
+        assert np.array_equal(part, mine, equal_nan=True)
+
+
+def test_full_size_properties(gpu_ctx):
+    """Size-independent checks at the benchmark's size (teapot, 3840x2160, 16 spp)."""
+    ctx = gpu_ctx("teapot")
+    w, h = 3840, 2160
+    ctx.reset_counters()
+    rgb, rgb8 = ctx.render(w, h, mode=rt.MODE_GRID, grid_m=4, max_depth=8)
+    c = ctx.counters()
+    # closed room, two lights, no reflective material: every primary ray hits something and casts 2 shadow rays
+    assert c.rays_primary == w * h * 16 and c.rays_shadow == 2 * c.rays_primary and c.rays_secondary == 0
+    assert np.isfinite(rgb).all() and rgb.min() >= 0
+    # idempotence
+    rgb_b, rgb8_b = ctx.render(w, h, mode=rt.MODE_GRID, grid_m=4, max_depth=8)
+    assert np.array_equal(rgb8, rgb8_b) and np.array_equal(rgb, rgb_b)
+    # the quantised image is the oracle's tone map + truncation of the linear image
+    sel = np.random.default_rng(0).integers(0, w * h, size=200000)
+    assert np.abs(O.tonemap_quantise(rgb.reshape(-1, 3)[sel]).astype(int) - rgb8.reshape(-1, 3)[sel].astype(int)).max() <= 1
+    # a 16-spp pixel is the mean of its taps: compare a crop against the oracle (few seconds of CPU)
+    x0, y0, cw, ch = 1320, 590, 64, 24  # across the teapot's left silhouette (x = 1353 on row 600)
+    osc = O.Scene("teapot")
+    ref_rgb, ref_rgb8, _ = osc.render(w, h, mode=2, grid_m=4, max_depth=8, rect=(x0, y0, x0 + cw, y0 + ch))
+    parity.check_radiance(ref_rgb[y0:y0 + ch, x0:x0 + cw], rgb[y0:y0 + ch, x0:x0 + cw], "4K crop")
+    parity.check_rgb8(ref_rgb8[y0:y0 + ch, x0:x0 + cw], rgb8[y0:y0 + ch, x0:x0 + cw], "4K crop")
+    # both the wall and the (red) teapot are in the crop
+    crop = rgb8[y0:y0 + ch, x0:x0 + cw].reshape(-1, 3).astype(int)
+    reddish = (crop[:, 0] > crop[:, 1] + 60).mean()
+    assert 0.1 < reddish < 0.9
+
+
+def test_error_paths(host_scene):
+    ctx = rt.Context(0)
+    with pytest.raises(rt.RtError, match="no scene"):
+        ctx.render(16, 16)
+    ctx.upload(host_scene("teapot"), build=False)
+    with pytest.raises(rt.RtError, match="rt_build_accel"):
+        ctx.render(16, 16, accel=rt.ACCEL_LBVH)
+    ctx.render(16, 16, accel=rt.ACCEL_BRUTE)  # the linear scan needs no tree
+    ctx.build_accel()
+    ctx.build_accel()  # idempotent
+    with pytest.raises(rt.RtError):
+        ctx.render(0, 16)
+    with pytest.raises(rt.RtError):
+        ctx.render(16, 16, max_depth=rt.MAX_DEPTH + 1)
+    with pytest.raises(rt.RtError):
+        ctx.intersect_object(99, np.zeros((1, 3)), np.ones((1, 3)))
+    bad = rt.SceneDesc.from_buffer_copy(host_scene("teapot").flatten().contents)
+    bad.n_materials = 0
+    with pytest.raises(rt.RtError, match="material"):
+        ctx.upload(C.pointer(bad))
+    ctx.close()
+
+
+def test_empty_and_tiny_meshes_on_gpu():
+    tri = np.array([[0, 0, 5, 0, 1, 5, 1, 0, 5], [1, 0, 5, 0, 1, 5, 1, 1, 5]], np.float32)
+    nrm = np.tile(np.array([0, 0, -1], np.float32), (2, 3))
+    o = np.array([[0.2, 0.2, 0], [0.8, 0.8, 0], [0.5, 0.5, 0], [0.2, 0.2, 0], [5, 5, 0]], np.float32)
+    d = np.array([[0, 0, 1], [0, 0, 1], [0, 0, 1], [np.nan, 0, 1], [0, 0, 1]], np.float32)
+    for n in (0, 1, 2):
+        hs = rt.HostScene()
+        hs.add_mesh_tris(tri[:n], nrm[:n], rt.mat_identity(), rt.Material(diffuse=(1, 0, 0)), boxed=False)
+        hs.add_light((0, 5, 0), 1.0)
+        ctx = rt.Context(0)
+        ctx.upload(hs)
+        hits, rad = ctx.trace_rays(o, d, max_depth=4)
+        want = [[0, 0, 0, 0, 0], [1, 0, 1, 0, 0], [1, 1, 1, 0, 0]][n]
+        assert list(hits["hit"]) == want
+        assert np.isfinite(rad).all()
+        ctx.close()

@@ -1,0 +1,147 @@
+"""Logic of the renderer (the per-ray code the HIP kernels run, compiled for the host by
+tests/cpu_twin) against the CPU oracle.  Runs without a GPU; the GPU tests repeat the same checks
+through the C ABI on the real kernels."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import parity
+import ray_tracer_amd as rt
+import twin_lib as T
+
+PRESETS = ["analytic", "teapot", "teapot_head", "shells", "textured"]
+_twins = {}
+
+
+@pytest.fixture(scope="module")
+def twin(host_scene):
+    def get(preset):
+        if preset not in _twins:
+            _twins[preset] = T.Twin(host_scene(preset))
+        return _twins[preset]
+    return get
+
+
+@pytest.mark.parametrize("preset", PRESETS)
+@pytest.mark.parametrize("accel", [rt.ACCEL_LBVH, rt.ACCEL_BRUTE])
+def test_rays_match_oracle(preset, accel, twin, oracle_scene, host_scene):
+    osc, tw = oracle_scene(preset), twin(preset)
+    o, d = parity.ray_set(osc, host_scene(preset).flatten().contents)
+    ref_hits = osc.find_closest_hit(o, d)
+    ref_rad, _ = osc.trace_rays(o, d, 8)
+    hits, rad = tw.trace_rays(o, d, 8, accel)
+    ties = parity.check_hits(ref_hits, hits, f"{preset}/accel{accel}")
+    assert ties == 0  # same arithmetic on the same CPU: not even grazing ties may differ
+    err = parity.check_radiance(ref_rad, rad, preset, frac=1.0)
+    assert err.max() <= 1e-6
+
+
+@pytest.mark.parametrize("preset", ["analytic", "teapot", "shells"])
+def test_per_object_intersect_matches_oracle(preset, twin, oracle_scene, host_scene):
+    osc, tw = oracle_scene(preset), twin(preset)
+    o, d = parity.ray_set(osc, host_scene(preset).flatten().contents, w=48, h=36, n_random=500)
+    for obj in range(osc.num_objects):
+        ref = osc.intersect_object(obj, o, d)
+        got = tw.intersect_object(obj, o, d)
+        far = np.array([parity.is_spurious_far_hit(r) for r in ref])
+        assert far.sum() <= 2e-3 * len(ref)
+        assert np.array_equal(ref["hit"][~far], got["hit"][~far]), (preset, obj)
+        m = (ref["hit"] == 1) & ~far
+        for f in ("frag", "sub", "from_outside"):
+            assert np.array_equal(ref[f][m], got[f][m]), (preset, obj, f)
+        for f in ("distance", "normal", "point", "uv"):
+            assert np.array_equal(ref[f][m], got[f][m]), (preset, obj, f)
+
+
+@pytest.mark.parametrize("preset,mode,grid", [("analytic", rt.MODE_REF_AA9, 1), ("teapot", rt.MODE_GRID, 2),
+                                              ("shells", rt.MODE_REF_1SPP, 1), ("textured", rt.MODE_REF_AA9, 1)])
+def test_frames_match_oracle(preset, mode, grid, twin, oracle_scene):
+    w, h = 64, 48
+    ref_rgb, ref_rgb8, ref_rays = oracle_scene(preset).render(w, h, mode=mode, grid_m=grid, max_depth=8)
+    rgb, rgb8, counters = twin(preset).render(w, h, mode=mode, grid_m=grid, max_depth=8)
+    parity.check_radiance(ref_rgb, rgb, preset, frac=1.0)
+    assert np.array_equal(ref_rgb8, rgb8)
+    assert int(counters[:3].sum()) == ref_rays  # same ray accounting: one ray per closest-hit query
+
+
+def test_lbvh_structure(twin, host_scene):
+    """Every triangle is a leaf exactly once, child boxes enclose their subtrees, height fits the stack."""
+    for preset in ("teapot", "shells"):
+        d = host_scene(preset).flatten().contents
+        tw = twin(preset)
+        pos_all = np.ctypeslib.as_array(d.tri_pos, shape=(d.n_triangles * 9,)).reshape(-1, 3, 3)
+        for mi in range(d.n_meshes):
+            m = d.meshes[mi]
+            nodes, order = tw.copy_bvh(mi, m.tri_count)
+            assert sorted(order) == list(range(m.tri_offset, m.tri_offset + m.tri_count))
+            children = nodes[:, 12:14].copy().view(np.int32)
+            seen_leaf, seen_node = np.zeros(m.tri_count, int), np.zeros(len(nodes), int)
+            lo = np.full((len(nodes), 3), np.inf); hi = np.full((len(nodes), 3), -np.inf)
+
+            def bounds(c):
+                if c < 0:
+                    seen_leaf[~c] += 1
+                    p = pos_all[order[~c]]
+                    return p.min(0), p.max(0), 0
+                seen_node[c] += 1
+                l0, h0, d0 = bounds(children[c, 0])
+                l1, h1, d1 = bounds(children[c, 1])
+                assert np.all(nodes[c, 0:3] <= l0) and np.all(nodes[c, 3:6] >= h0)
+                assert np.all(nodes[c, 6:9] <= l1) and np.all(nodes[c, 9:12] >= h1)
+                return np.minimum(l0, l1), np.maximum(h0, h1), 1 + max(d0, d1)
+
+            import sys
+            sys.setrecursionlimit(10000)
+            _, _, height = bounds(0)
+            assert np.all(seen_leaf == 1) and np.all(seen_node == 1)
+            assert height <= 40
+        assert tw.height <= 40
+
+
+def test_degenerate_meshes(oracle_scene):
+    """Zero, one and two triangles; a NaN ray; rays parallel to the triangle plane."""
+    tri = np.array([[0, 0, 5, 0, 1, 5, 1, 0, 5], [1, 0, 5, 0, 1, 5, 1, 1, 5]], np.float32)
+    nrm = np.tile(np.array([0, 0, -1], np.float32), (2, 3))
+    rays_o = np.array([[0.2, 0.2, 0], [0.8, 0.8, 0], [0.5, 0.5, 0], [0.2, 0.2, 0], [0.2, 0.2, 5], [5, 5, 0]], np.float32)
+    rays_d = np.array([[0, 0, 1], [0, 0, 1], [0, 0, 1], [np.nan, 0, 1], [1, 0, 0], [0, 0, 1]], np.float32)
+    for n in (0, 1, 2):
+        hs = rt.HostScene()
+        hs.add_mesh_tris(tri[:n], nrm[:n], rt.mat_identity(), rt.Material(diffuse=(1, 0, 0)), boxed=False)
+        hs.add_light((0, 5, 0), 1.0)
+        osc = O.Scene()
+        mat = O.OrcMaterial(); osc.L.orc_material_default(C_byref(mat)); mat.diffuse[:] = (1, 0, 0)
+        I = rt.mat_identity()
+        osc.L.orc_add_mesh_tris(osc.h, n, tri[:n].ctypes.data if n else None, nrm[:n].ctypes.data if n else None, None,
+                                I.ctypes.data, C_byref(mat), 0)
+        lp = np.array([0, 5, 0], np.float32); lc = np.ones(3, np.float32)
+        osc.L.orc_add_light(osc.h, lp.ctypes.data, lc.ctypes.data)
+        tw = T.Twin(hs)
+        for accel in (rt.ACCEL_LBVH, rt.ACCEL_BRUTE):
+            hits, rad = tw.trace_rays(rays_o, rays_d, 4, accel)
+            ref = osc.find_closest_hit(rays_o, rays_d)
+            ref_rad, _ = osc.trace_rays(rays_o, rays_d, 4)
+            parity.check_hits(ref, hits, f"n={n}")
+            assert np.array_equal(ref_rad, rad)
+        if n == 2:
+            assert list(ref["hit"]) == [1, 1, 1, 0, 0, 0]
+            assert ref["frag"][2] in (0, 1)  # the shared diagonal: decided by the tie rule, equal on both sides
+
+
+def C_byref(x):
+    import ctypes
+    return ctypes.byref(x)
+
+
+def test_invalid_scene_rejected(host_scene):
+    import copy
+    import ctypes as C
+    d = host_scene("teapot").flatten().contents
+    bad = rt.SceneDesc.from_buffer_copy(d)
+    bad.n_materials = 0
+    err = C.create_string_buffer(256)
+    assert not T.lib().twin_create(C.byref(bad), err, 256) and b"material" in err.value
+    bad = rt.SceneDesc.from_buffer_copy(d)
+    meshes = (rt.Mesh * 1)(d.meshes[0])
+    meshes[0].tri_count = d.n_triangles + 1
+    bad.meshes = meshes
+    assert not T.lib().twin_create(C.byref(bad), err, 256) and b"range" in err.value
