@@ -132,6 +132,8 @@ _host = None
 
 def _load(name):
     path = os.path.join(_HERE, name)
+    if name == "librt_amd.so" and os.environ.get("RT_AMD_LIB"):
+        path = os.environ["RT_AMD_LIB"]  # development: A/B another build of the same library
     if not os.path.exists(path):
         raise RtError(f"{path} is missing: build it with `make -C ray_tracer_amd/csrc` "
                       "(or __graft_entry__.build())")

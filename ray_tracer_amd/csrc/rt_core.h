@@ -28,7 +28,7 @@ namespace rtc {
 
 constexpr float kEps = 0.0001f;     // EPS, main.cpp:23
 constexpr float kMinDist = 0.01f;   // find_closest_hit threshold, main.cpp:705
-constexpr int kStackDepth = 40;     // LBVH traversal stack entries per ray
+constexpr int kStackDepth = 32;     // LBVH traversal stack entries per ray
 constexpr double kPi = 3.14159265358979323846;
 
 struct v2 { float x, y; };
@@ -54,6 +54,13 @@ RT_HD v3 normalize(v3 v) { return v * (1.0f / sqrtf(dot(v, v))); }
 RT_HD float distance(v3 p0, v3 p1) { return length(p1 - p0); }
 // func_geometric.inl:106-109
 RT_HD v3 reflect(v3 I, v3 N) { return I - (N * dot(N, I)) * 2.0f; }
+RT_HD int32_t f2i(float f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __float_as_int(f);
+#else
+    int32_t i; __builtin_memcpy(&i, &f, 4); return i;
+#endif
+}
 RT_HD bool has_nan(v3 a) { return !(a.x == a.x) || !(a.y == a.y) || !(a.z == a.z); }
 
 // mat4 * vec4 of glm/detail/type_mat4x4.inl:561-572 on a matrix stored as four 3-row columns:
@@ -64,7 +71,8 @@ RT_HD v3 xform(const float *m, v3 p, float w) {
     return add0 + add1;
 }
 RT_HD v3 xform_point(const float *m, v3 p) { return xform(m, p, 1.0f); }
-RT_HD v3 xform_dir(const float *m, v3 p) { return xform(m, p, 0.0f); }
+// w = 0: the translation column contributes c3 * 0 = +-0, which can only change the sign of a zero
+RT_HD v3 xform_dir(const float *m, v3 p) { return (ld3(m) * p.x + ld3(m + 3) * p.y) + ld3(m + 6) * p.z; }
 // mat3(c0,c1,c2) * v, glm/detail/type_mat3x3.inl:468-474
 RT_HD v3 m3_mul(v3 c0, v3 c1, v3 c2, v3 v) {
     return V3(c0.x * v.x + c1.x * v.y + c2.x * v.z, c0.y * v.x + c1.y * v.y + c2.y * v.z,
@@ -83,7 +91,8 @@ struct BvhNode {  // 64 bytes: both children's boxes, then the children
 
 struct DevMesh {
     float to_local[12], to_world[12], normal_mat[12], box_to_local[12];
-    float gate_lo[3], gate_hi[3];  // padded Box bounds for the conservative pre-test
+    float gate_lo[3], gate_hi[3];        // padded Box bounds for the conservative pre-test
+    float gate_in_lo[3], gate_in_hi[3];  // shrunken Box bounds: an origin inside sees only back faces
     int32_t tri_offset, tri_count, boxed, node_offset;
     int32_t gate_tri_offset;  // first of this mesh's 12 gate triangles in DevScene::gate_tri
     int32_t pad[3];
@@ -98,7 +107,9 @@ struct DevTexture {
 
 struct DevScene {
     int32_t n_objects, n_lights;
+    int32_t n_planes, n_spheres, n_cones, n_meshes;
     const rt_object *objects;
+    const int32_t *plane_obj, *sphere_obj, *cone_obj, *mesh_obj;  // index of each plane / ... in `objects`
     const rt_sphere *spheres;
     const rt_plane *planes;
     const rt_cone *cones;
@@ -191,10 +202,9 @@ struct Surf {  // a resolved hit (Hit, main.cpp:45-53)
 RT_HD bool plane_hit(const rt_plane &pl, v3 ro, v3 rd, float &t) {
     v3 n = ld3(pl.normal);
     float DdotN = dot(rd, n);
-    if (!(DdotN < 0)) return false;
     float PdotN = dot(ld3(pl.point) - ro, n);
-    t = PdotN / DdotN;
-    return t > 0;
+    t = PdotN / DdotN;  // evaluated unconditionally (no divergent exit); only used when DdotN < 0
+    return (DdotN < 0) & (t > 0);
 }
 template <bool COUNT>
 RT_HD void plane_surface(const DevScene &S, const rt_plane &pl, v3 ro, v3 rd, float t, Surf &s, Work &wk) {
@@ -412,42 +422,81 @@ RT_HD bool slab(const float *lo, const float *hi, v3 o, v3 inv, float tmax, floa
     return tn <= tf * 1.0000004f;
 }
 
-// Closest triangle of a mesh for a local-space ray: stack traversal of the mesh's LBVH.
-// Stack is any type with push(int) / pop() / empty().
+RT_HD float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+RT_HD float safe_rcp(float x) { return fabsf(x) >= 1e-30f ? 1.0f / x : copysignf(1e30f, x); }
+
+// The same test in fused form for the traversal loop: t = bound * inv - o * inv.  The boxes of the
+// tree are padded by ~100 ulps of the mesh's largest coordinate, far more than the rounding
+// difference between the fused and the unfused form, so the test stays conservative.
+RT_HD bool slab_fused(float lox, float loy, float loz, float hix, float hiy, float hiz, v3 inv, v3 oi, float tmax, float &tnear) {
+    float ax = fma_(lox, inv.x, -oi.x), bx = fma_(hix, inv.x, -oi.x);
+    float ay = fma_(loy, inv.y, -oi.y), by = fma_(hiy, inv.y, -oi.y);
+    float az = fma_(loz, inv.z, -oi.z), bz = fma_(hiz, inv.z, -oi.z);
+    float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
+    float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tmax));
+    tnear = tn;
+    return tn <= tf;
+}
+
+// Branch-free form of tri_test for the traversal loop: every lane that holds a leaf runs the whole
+// test and the outcome is folded into one predicate (identical decisions, no divergent exits).
+template <bool COUNT>
+RT_HD void tri_test_flat(const f4 *tt, int32_t k, uint32_t key, v3 o, v3 d, TriBest &best, Work &wk) {
+    if (COUNT) wk.tri++;
+    f4 A = tt[3 * k], B = tt[3 * k + 1], C = tt[3 * k + 2];
+    v3 p1 = V3(A.x, A.y, A.z), p2 = V3(A.w, B.x, B.y), p3 = V3(B.z, B.w, C.x), sn = V3(C.y, C.z, C.w);
+    float DdotN = dot(d, sn);
+    float PdotN = dot(p1 - o, sn);
+    float t = PdotN / DdotN;
+    bool ok = (DdotN < 0) & (t > 0) & !((t > best.t) | ((t == best.t) & (key > best.key)));
+    v3 p = d * t + o;
+    v3 sn1 = cross(p2 - p, p3 - p);
+    v3 sn2 = cross(p3 - p, p1 - p);
+    v3 sn3 = cross(p1 - p, p2 - p);
+    ok = ok & !((dot(sn1, sn) < 0) | (dot(sn2, sn) < 0) | (dot(sn3, sn) < 0));
+    best.t = ok ? t : best.t;
+    best.k = ok ? k : best.k;
+    best.key = ok ? key : best.key;
+}
+
+constexpr int32_t kTraversalDone = 0x7fffffff;
+
+// Closest triangle of a mesh for a local-space ray: stack traversal of the mesh's LBVH in
+// "while-while" form -- every lane walks inner nodes until it holds a leaf (or is finished), then
+// the lanes holding leaves test their triangles together.  Near child first, far child pushed; a
+// child is skipped when its entry distance exceeds the best t so far (ties are kept so that the
+// tie-break on keys sees every candidate).
+// Stack is any type with reset() / push(int) / pop() / empty().
 template <bool COUNT, class Stack>
 RT_HD void bvh_closest(const DevScene &S, const DevMesh &m, v3 o, v3 d, TriBest &best, Stack &stk, Work &wk) {
     const BvhNode *nodes = S.nodes + m.node_offset;
     const f4 *tt = S.tri_test + 3 * (size_t)m.tri_offset;
     const uint32_t *keys = S.tri_key + m.tri_offset;
-    v3 inv = V3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    // A zero direction component would give inf - inf = NaN in the fused slab test; a huge finite
+    // reciprocal keeps the sign logic (the ray then counts as parallel to that slab).
+    v3 inv = V3(safe_rcp(d.x), safe_rcp(d.y), safe_rcp(d.z));
+    v3 oi = o * inv;
     stk.reset();
-    int32_t cur = 0;
-    if (m.tri_count == 1) cur = ~0;
-    for (;;) {
+    int32_t cur = m.tri_count == 1 ? ~0 : 0;
+    while (cur != kTraversalDone) {
+        while (cur >= 0 && cur != kTraversalDone) {
+            const f4 *np = reinterpret_cast<const f4 *>(nodes + cur);
+            f4 a = np[0], b = np[1], c = np[2], e = np[3];
+            if (COUNT) wk.box += 2;
+            float n0, n1;
+            bool h0 = slab_fused(a.x, a.y, a.z, a.w, b.x, b.y, inv, oi, best.t, n0);
+            bool h1 = slab_fused(b.z, b.w, c.x, c.y, c.z, c.w, inv, oi, best.t, n1);
+            int32_t c0 = f2i(e.x), c1 = f2i(e.y);
+            bool second_first = h1 & (!h0 | (n1 < n0));
+            int32_t nearc = second_first ? c1 : c0, farc = second_first ? c0 : c1;
+            if (h0 & h1) stk.push(farc);
+            if (h0 | h1) cur = nearc;
+            else cur = stk.empty() ? kTraversalDone : stk.pop();
+        }
         if (cur < 0) {
             int32_t k = ~cur;
-            tri_test<COUNT>(tt, k, keys[k], o, d, best, wk);
-            if (stk.empty()) break;
-            cur = stk.pop();
-            continue;
-        }
-        const BvhNode &nd = nodes[cur];
-        if (COUNT) wk.box += 2;
-        float n0, n1;
-        bool h0 = slab(nd.lo0, nd.hi0, o, inv, best.t, n0);
-        bool h1 = slab(nd.lo1, nd.hi1, o, inv, best.t, n1);
-        if (h0 && h1) {
-            int32_t nearc = nd.c0, farc = nd.c1;
-            if (n1 < n0) { nearc = nd.c1; farc = nd.c0; }
-            stk.push(farc);
-            cur = nearc;
-        } else if (h0) {
-            cur = nd.c0;
-        } else if (h1) {
-            cur = nd.c1;
-        } else {
-            if (stk.empty()) break;
-            cur = stk.pop();
+            tri_test_flat<COUNT>(tt, k, keys[k], o, d, best, wk);
+            cur = stk.empty() ? kTraversalDone : stk.pop();
         }
     }
 }
@@ -456,33 +505,41 @@ RT_HD void bvh_closest(const DevScene &S, const DevMesh &m, v3 o, v3 d, TriBest 
 // the acceptance inputs of find_closest_hit.
 struct MeshHit {
     float t;        // local ray parameter (Triangle's `distance`)
-    int32_t k;      // sorted triangle position
+    int32_t k;      // sorted triangle position (scene-wide)
     float distance; // Euclidean, world space (main.cpp:545)
     bool from_outside;
-    v3 o, d;        // local ray
 };
 
+// clip: hits with a local ray parameter beyond it cannot matter to the caller (shadow rays: the
+// light's distance); INFINITY for radiance rays.  The closest triangle within the clip range is
+// the mesh's closest triangle whenever that one lies within the range, so the result the caller
+// uses is unchanged.
+//
+// Box gate = "some one-sided Box face is hit".  Evaluated as: (1) a conservative slab test on the
+// padded box rejects rays that pass it by; (2) a ray whose origin lies strictly inside the box
+// only sees back faces, so the gate is closed; (3) for the remaining rays the tree is searched
+// first and the 12 exact triangle tests run only for rays that found a triangle (the gate is a
+// conjunct of the result, so the order does not matter).
 template <bool COUNT, class Stack>
-RT_HD bool mesh_geom(const DevScene &S, const DevMesh &m, v3 ro, v3 rd, int accel, MeshHit &mh, Stack &stk, Work &wk) {
+RT_HD bool mesh_geom(const DevScene &S, const DevMesh &m, v3 ro, v3 rd, int accel, float clip, MeshHit &mh, Stack &stk, Work &wk) {
     if (m.tri_count <= 0) return false;
     if (has_nan(ro) || has_nan(rd)) return false;  // every triangle test fails on NaN inputs
+    v3 bo = ro, bd = rd;
     if (m.boxed) {
-        v3 bd = xform_dir(m.box_to_local, rd);
-        v3 bo = xform_point(m.box_to_local, ro);
+        bd = xform_dir(m.box_to_local, rd);
+        bo = xform_point(m.box_to_local, ro);
         v3 binv = V3(1.0f / bd.x, 1.0f / bd.y, 1.0f / bd.z);
         float tn;
         if (COUNT) wk.box++;
         if (!slab(m.gate_lo, m.gate_hi, bo, binv, INFINITY, tn)) return false;
-        if (COUNT) wk.gate++;
-        const f4 *gt = S.gate_tri + 3 * (size_t)m.gate_tri_offset;
-        bool any = false;
-        for (int i = 0; i < 12; i++) any = any || tri_hits(gt, i, bo, bd);
-        if (!any) return false;
+        if (bo.x > m.gate_in_lo[0] && bo.x < m.gate_in_hi[0] && bo.y > m.gate_in_lo[1] && bo.y < m.gate_in_hi[1] &&
+            bo.z > m.gate_in_lo[2] && bo.z < m.gate_in_hi[2])
+            return false;
     }
     v3 d = xform_dir(m.to_local, rd);
     v3 o = xform_point(m.to_local, ro);
     TriBest best;
-    best.t = INFINITY; best.k = -1; best.key = 0xffffffffu;
+    best.t = clip; best.k = -1; best.key = 0xffffffffu;
     if (accel == RT_ACCEL_BRUTE) {
         const f4 *tt = S.tri_test + 3 * (size_t)m.tri_offset;
         const uint32_t *keys = S.tri_key + m.tri_offset;
@@ -491,17 +548,25 @@ RT_HD bool mesh_geom(const DevScene &S, const DevMesh &m, v3 ro, v3 rd, int acce
         bvh_closest<COUNT>(S, m, o, d, best, stk, wk);
     }
     if (best.k < 0) return false;
+    if (m.boxed) {
+        if (COUNT) wk.gate++;
+        const f4 *gt = S.gate_tri + 3 * (size_t)m.gate_tri_offset;
+        bool any = false;
+        for (int i = 0; i < 12; i++) any = any || tri_hits(gt, i, bo, bd);
+        if (!any) return false;
+    }
     mh.t = best.t;
     mh.k = best.k + m.tri_offset;
-    mh.o = o; mh.d = d;
     v3 p, n; v2 uv; int32_t orig;
     tri_surface(S, mh.k, mh.t, o, d, p, n, uv, mh.from_outside, orig);
     mh.distance = distance(ro, xform_point(m.to_world, p));
     return true;
 }
-RT_HD void mesh_surface(const DevScene &S, const DevMesh &m, const MeshHit &mh, Surf &s) {
+RT_HD void mesh_surface(const DevScene &S, const DevMesh &m, v3 ro, v3 rd, float t, int32_t k, Surf &s) {
+    v3 d = xform_dir(m.to_local, rd);
+    v3 o = xform_point(m.to_local, ro);
     v3 p, n; int32_t orig;
-    tri_surface(S, mh.k, mh.t, mh.o, mh.d, p, n, s.uv, s.from_outside, orig);
+    tri_surface(S, k, t, o, d, p, n, s.uv, s.from_outside, orig);
     s.point = xform_point(m.to_world, p);
     s.normal = normalize(xform_dir(m.normal_mat, n));
     s.material = S.tri_material[orig];
@@ -511,45 +576,63 @@ RT_HD void mesh_surface(const DevScene &S, const DevMesh &m, const MeshHit &mh, 
 
 // ---------------------------------------------------------------- closest hit
 
+// The winner of find_closest_hit, reduced to what is needed to rebuild the full hit record:
+// t is the ray parameter in the object's own space; k is the sorted triangle position (mesh) or
+// 1 for a cone's cap plane.
 struct Closest {
     float distance;
     int32_t object;  // -1: miss
-    // what is needed to resolve the winner without repeating the search
     float t;
     int32_t k;
-    bool cap, from_outside;
-    v3 o, d, i;
 };
 
-// find_closest_hit, main.cpp:697-709: objects in list order, strict `<` keeps the first of equals
+// find_closest_hit, main.cpp:697-709.  The reference walks the object list in order and keeps the
+// first of equal distances; here objects are visited kind by kind (planes, quadrics, meshes) and a
+// candidate replaces the best when its distance is smaller, or equal with a smaller object index,
+// which selects the same object.
+// occl: a shadow ray only needs to know whether something accepted lies closer than the light;
+// once the best distance is below occl the (expensive) meshes are skipped.  -INFINITY disables it.
+RT_HD bool closer(float dist, int32_t idx, const Closest &best) {
+    return (dist > kMinDist) & ((dist < best.distance) | ((dist == best.distance) & (idx < best.object)));
+}
 template <bool COUNT, class Stack>
-RT_HD void find_closest(const DevScene &S, v3 ro, v3 rd, int accel, Closest &best, Stack &stk, Work &wk) {
+RT_HD void find_closest(const DevScene &S, v3 ro, v3 rd, int accel, float clip, float occl, Closest &best, Stack &stk, Work &wk) {
     best.distance = INFINITY;
     best.object = -1;
-    for (int32_t k = 0; k < S.n_objects; k++) {
-        rt_object ob = S.objects[k];
-        if (ob.kind == RT_OBJ_PLANE) {
-            float t;
-            if (COUNT) wk.plane++;
-            if (plane_hit(S.planes[ob.index], ro, rd, t) && t > kMinDist && t < best.distance) {
-                best.distance = t; best.object = k; best.t = t; best.from_outside = true;
-            }
-        } else if (ob.kind == RT_OBJ_MESH) {
-            MeshHit mh;
-            if (mesh_geom<COUNT>(S, S.meshes[ob.index], ro, rd, accel, mh, stk, wk) && mh.from_outside &&
-                mh.distance > kMinDist && mh.distance < best.distance) {
-                best.distance = mh.distance; best.object = k; best.t = mh.t; best.k = mh.k;
-                best.o = mh.o; best.d = mh.d; best.from_outside = true;
-            }
-        } else {
-            QuadricHit q;
-            if (COUNT) wk.quadric++;
-            bool hit = ob.kind == RT_OBJ_SPHERE ? sphere_geom(S.spheres[ob.index], ro, rd, q)
-                                                : cone_geom(S.cones[ob.index], ro, rd, q);
-            if (hit && q.from_outside && q.distance > kMinDist && q.distance < best.distance) {
-                best.distance = q.distance; best.object = k; best.t = q.t; best.cap = q.cap;
-                best.o = q.o; best.d = q.d; best.i = q.i; best.from_outside = q.from_outside;
-            }
+    best.t = 0;
+    best.k = 0;
+    for (int32_t i = 0; i < S.n_planes; i++) {
+        float t;
+        if (COUNT) wk.plane++;
+        int32_t idx = S.plane_obj[i];
+        if (idx < 0) continue;  // not in the object list
+        bool ok = plane_hit(S.planes[i], ro, rd, t) & closer(t, idx, best);
+        best.distance = ok ? t : best.distance; best.object = ok ? idx : best.object; best.t = ok ? t : best.t; best.k = ok ? 0 : best.k;
+    }
+    for (int32_t i = 0; i < S.n_spheres; i++) {
+        QuadricHit q;
+        if (COUNT) wk.quadric++;
+        int32_t idx = S.sphere_obj[i];
+        if (idx < 0) continue;
+        if (sphere_geom(S.spheres[i], ro, rd, q) && q.from_outside && closer(q.distance, idx, best)) {
+            best.distance = q.distance; best.object = idx; best.t = q.t; best.k = 0;
+        }
+    }
+    for (int32_t i = 0; i < S.n_cones; i++) {
+        QuadricHit q;
+        if (COUNT) wk.quadric++;
+        int32_t idx = S.cone_obj[i];
+        if (idx < 0) continue;
+        if (cone_geom(S.cones[i], ro, rd, q) && closer(q.distance, idx, best)) {
+            best.distance = q.distance; best.object = idx; best.t = q.t; best.k = q.cap ? 1 : 0;
+        }
+    }
+    for (int32_t i = 0; i < S.n_meshes; i++) {
+        int32_t idx = S.mesh_obj[i];
+        if (idx < 0 || best.distance < occl) continue;
+        MeshHit mh;
+        if (mesh_geom<COUNT>(S, S.meshes[i], ro, rd, accel, clip, mh, stk, wk) && mh.from_outside && closer(mh.distance, idx, best)) {
+            best.distance = mh.distance; best.object = idx; best.t = mh.t; best.k = mh.k;
         }
     }
 }
@@ -560,14 +643,34 @@ RT_HD void resolve(const DevScene &S, const Closest &c, v3 ro, v3 rd, Surf &s, W
     if (ob.kind == RT_OBJ_PLANE) {
         plane_surface<COUNT>(S, S.planes[ob.index], ro, rd, c.t, s, wk);
     } else if (ob.kind == RT_OBJ_MESH) {
-        MeshHit mh;
-        mh.t = c.t; mh.k = c.k; mh.o = c.o; mh.d = c.d;
-        mesh_surface(S, S.meshes[ob.index], mh, s);
-    } else {
+        mesh_surface(S, S.meshes[ob.index], ro, rd, c.t, c.k, s);
+    } else if (ob.kind == RT_OBJ_SPHERE) {
+        const rt_sphere &sp = S.spheres[ob.index];
         QuadricHit q;
-        q.t = c.t; q.cap = c.cap; q.o = c.o; q.d = c.d; q.i = c.i; q.from_outside = c.from_outside;
-        if (ob.kind == RT_OBJ_SPHERE) sphere_surface<COUNT>(S, S.spheres[ob.index], q, s, wk);
-        else cone_surface<COUNT>(S, S.cones[ob.index], q, s, wk);
+        q.o = xform_point(sp.to_local, ro); q.d = xform_dir(sp.to_local, rd);
+        q.t = c.t; q.cap = false; q.i = q.o + q.d * c.t;
+        q.from_outside = !(fabsf(q.o.x) < 1 && fabsf(q.o.y) < 1 && fabsf(q.o.z) < 1);
+        sphere_surface<COUNT>(S, sp, q, s, wk);
+    } else {
+        const rt_cone &cn = S.cones[ob.index];
+        QuadricHit q;
+        q.d = xform_dir(cn.to_local, rd); q.o = xform_point(cn.to_local, ro);
+        q.t = c.t; q.cap = c.k != 0; q.from_outside = true;
+        q.i = q.cap ? q.d * c.t + q.o : q.o + q.d * c.t;
+        cone_surface<COUNT>(S, cn, q, s, wk);
+    }
+}
+
+RT_HD void fill_hit(rt_hit_record &h, const Closest &c, const Surf &s) {
+    h.hit = c.object >= 0; h.object = c.object; h.from_outside = 1; h.distance = c.distance;
+    h.frag = 0; h.sub = 0;
+    for (int i = 0; i < 3; i++) { h.normal[i] = 0; h.point[i] = 0; }
+    h.uv[0] = h.uv[1] = 0;
+    if (c.object >= 0) {
+        h.frag = s.frag; h.sub = s.sub; h.from_outside = s.from_outside ? 1 : 0;
+        h.normal[0] = s.normal.x; h.normal[1] = s.normal.y; h.normal[2] = s.normal.z;
+        h.point[0] = s.point.x; h.point[1] = s.point.y; h.point[2] = s.point.z;
+        h.uv[0] = s.uv.x; h.uv[1] = s.uv.y;
     }
 }
 
@@ -575,7 +678,8 @@ RT_HD void resolve(const DevScene &S, const Closest &c, v3 ro, v3 rd, Surf &s, W
 template <bool COUNT, class Stack>
 RT_HD void intersect_object(const DevScene &S, int32_t k, v3 ro, v3 rd, int accel, rt_hit_record &out, Stack &stk, Work &wk) {
     Closest c;
-    c.object = -1; c.distance = INFINITY; c.from_outside = true;
+    c.object = -1; c.distance = INFINITY; c.t = 0; c.k = 0;
+    bool from_outside = true;
     rt_object ob = S.objects[k];
     bool hit = false;
     if (ob.kind == RT_OBJ_PLANE) {
@@ -584,29 +688,23 @@ RT_HD void intersect_object(const DevScene &S, int32_t k, v3 ro, v3 rd, int acce
         c.t = t; c.distance = t;
     } else if (ob.kind == RT_OBJ_MESH) {
         MeshHit mh;
-        hit = mesh_geom<COUNT>(S, S.meshes[ob.index], ro, rd, accel, mh, stk, wk);
-        if (hit) { c.t = mh.t; c.k = mh.k; c.o = mh.o; c.d = mh.d; c.distance = mh.distance; c.from_outside = mh.from_outside; }
+        hit = mesh_geom<COUNT>(S, S.meshes[ob.index], ro, rd, accel, INFINITY, mh, stk, wk);
+        if (hit) { c.t = mh.t; c.k = mh.k; c.distance = mh.distance; from_outside = mh.from_outside; }
     } else {
         QuadricHit q;
         hit = ob.kind == RT_OBJ_SPHERE ? sphere_geom(S.spheres[ob.index], ro, rd, q) : cone_geom(S.cones[ob.index], ro, rd, q);
-        if (hit) { c.t = q.t; c.cap = q.cap; c.o = q.o; c.d = q.d; c.i = q.i; c.distance = q.distance; c.from_outside = q.from_outside; }
+        if (hit) { c.t = q.t; c.k = q.cap ? 1 : 0; c.distance = q.distance; from_outside = q.from_outside; }
     }
-    out.hit = hit ? 1 : 0;
-    out.object = hit ? k : -1;
-    out.frag = 0; out.sub = 0;
-    out.from_outside = c.from_outside ? 1 : 0;
-    out.distance = hit ? c.distance : INFINITY;
-    for (int i = 0; i < 3; i++) { out.normal[i] = 0; out.point[i] = 0; }
-    out.uv[0] = out.uv[1] = 0;
+    Surf s;
+    s.frag = 0; s.sub = 0; s.from_outside = from_outside;
+    s.point = V3(0, 0, 0); s.normal = V3(0, 0, 0); s.uv.x = s.uv.y = 0;
     if (hit) {
         c.object = k;
-        Surf s;
         resolve<COUNT>(S, c, ro, rd, s, wk);
-        out.frag = s.frag; out.sub = s.sub;
-        out.normal[0] = s.normal.x; out.normal[1] = s.normal.y; out.normal[2] = s.normal.z;
-        out.point[0] = s.point.x; out.point[1] = s.point.y; out.point[2] = s.point.z;
-        out.uv[0] = s.uv.x; out.uv[1] = s.uv.y;
     }
+    fill_hit(out, c, s);
+    out.from_outside = from_outside ? 1 : 0;
+    if (!hit) out.distance = INFINITY;
 }
 
 // ---------------------------------------------------------------- shading
@@ -620,122 +718,203 @@ RT_HD v3 refract_dir(v3 i, v3 n, float index) {
     return a * alpha + b * beta;
 }
 
-// PhongModel, main.cpp:642-695.  The texture lookups do not depend on the light and are hoisted.
-template <bool COUNT, class Stack>
-RT_HD v3 phong(const DevScene &S, const Surf &s, v3 view, int accel, Stack &stk, Work &wk) {
-    const rt_material &m = S.materials[s.material];
-    v3 color = ld3(S.ambient) * ld3(m.ambient);
-    const DevTexture *tex = m.texture >= 0 ? &S.textures[m.texture] : nullptr;
-    const DevTexture *img = (tex && tex->kind == RT_TEX_IMAGE) ? tex : nullptr;
-    v3 dc = ld3(m.diffuse);
-    if (tex) dc = tex_color<COUNT>(*tex, s.uv, wk);
-    float shininess = m.shininess;
-    if (img) shininess = (float)(.5 / pow((double)tex_rgba<COUNT>(*img, 3, s.uv, wk).x, 4.0) - .5);
-    v3 spec_col = ld3(m.specular);
-    for (int l = 0; l < S.n_lights; l++) {
-        v3 lp = ld3(S.light_pos + 3 * l);
-        v3 L = normalize(lp - s.point);
-        wk.rays_shadow++;
-        Closest sh;
-        find_closest<COUNT>(S, s.point + L * kEps, L, accel, sh, stk, wk);
-        if (sh.distance < distance(s.point, lp)) continue;
-        if (COUNT) wk.shade++;
-        v3 R = reflect(-L, s.normal);
-        float NdotL = clamp01(dot(s.normal, L));
-        float VdotR = clamp01(dot(view, R));
-        v3 diffuse = dc * V3(NdotL, NdotL, NdotL);
-        if (img) diffuse = diffuse * 5.f;
-        float sp = powf(VdotR, shininess);
-        v3 specular = spec_col * V3(sp, sp, sp);
-        float r = distance(s.point, lp);
-        r = (r < 0.1f) ? 0.1f : r;
-        v3 term = ld3(S.light_color + 3 * l) * (diffuse + specular);
-        term = term * 1.3f;
-        term = term / r;
-        term = term / r;
-        color = color + term;
+// Shading-only arithmetic.  Decisions (which object is hit, shadowed or not) and every value that
+// feeds a later ray use the reference's exact operations above; the colour arithmetic below may
+// use the hardware's 1-ulp reciprocal and exp2/log2 on the GPU, which stays orders of magnitude
+// inside the 1e-4 relative radiance bar.
+RT_HD float shade_rcp(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rcpf(x);
+#else
+    return 1.0f / x;
+#endif
+}
+// pow(x, y) for x in [0, 1], y >= 0 (Phong lobe, main.cpp:678)
+RT_HD float shade_pow(float x, float y) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (y <= 256.0f) {
+        if (y == 0.0f) return 1.0f;
+        return __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x));
     }
-    if (img) color = color * tex_rgb<COUNT>(*img, 2, s.uv, wk);
-    else color = color * 4.0f;
-    color = color * 2.0f;
-    return color;
+#endif
+    return powf(x, y);
 }
 
-// trace_ray, main.cpp:716-761, as a loop.  The reference's result is linear in the radiance of
+// What PhongModel (main.cpp:642-695) needs while the shadow rays of one hit are in flight.
+struct ShadeCtx {
+    v3 point, normal, d_in;  // d_in: direction of the ray that produced the hit
+    v3 color;                // running sum, starts at ambient_light * material.ambient
+    v3 dc;                   // diffuse colour (texture(uv) or material.diffuse), x5 for image textures
+    v2 uv;
+    float shininess;
+    int32_t material;
+    bool from_outside;
+};
+
+template <bool COUNT>
+RT_HD void shade_begin(const DevScene &S, const Surf &s, v3 d_in, ShadeCtx &sc, Work &wk) {
+    const rt_material &m = S.materials[s.material];
+    sc.point = s.point; sc.normal = s.normal; sc.d_in = d_in; sc.uv = s.uv;
+    sc.material = s.material; sc.from_outside = s.from_outside;
+    sc.color = ld3(S.ambient) * ld3(m.ambient);
+    const DevTexture *tex = m.texture >= 0 ? &S.textures[m.texture] : nullptr;
+    const DevTexture *img = (tex && tex->kind == RT_TEX_IMAGE) ? tex : nullptr;
+    sc.dc = ld3(m.diffuse);
+    if (tex) sc.dc = tex_color<COUNT>(*tex, s.uv, wk);
+    sc.shininess = m.shininess;
+    if (img) {
+        sc.dc = sc.dc * 5.f;  // diffuse *= 5 (main.cpp:673) commutes with the NdotL factor
+        sc.shininess = (float)(.5 / pow((double)tex_rgba<COUNT>(*img, 3, s.uv, wk).x, 4.0) - .5);
+    }
+}
+// one light's contribution (main.cpp:658-685); L is the normalised direction to the light
+template <bool COUNT>
+RT_HD void shade_light(const DevScene &S, ShadeCtx &sc, int l, v3 L, float r, Work &wk) {
+    if (COUNT) wk.shade++;
+    const rt_material &m = S.materials[sc.material];
+    v3 view = normalize(-sc.d_in);
+    v3 R = reflect(-L, sc.normal);
+    float NdotL = clamp01(dot(sc.normal, L));
+    float VdotR = clamp01(dot(view, R));
+    v3 term = sc.dc * NdotL;
+    v3 spec_col = ld3(m.specular);
+    if (spec_col.x != 0.0f || spec_col.y != 0.0f || spec_col.z != 0.0f) term = term + spec_col * shade_pow(VdotR, sc.shininess);
+    r = (r < 0.1f) ? 0.1f : r;
+    float inv_r = shade_rcp(r);
+    term = ld3(S.light_color + 3 * l) * term;
+    sc.color = sc.color + term * (1.3f * inv_r * inv_r);
+}
+template <bool COUNT>
+RT_HD v3 shade_end(const DevScene &S, const ShadeCtx &sc, Work &wk) {
+    const rt_material &m = S.materials[sc.material];
+    const DevTexture *img = image_texture_of(S, m);
+    v3 color = sc.color;
+    if (img) color = color * tex_rgb<COUNT>(*img, 2, sc.uv, wk);
+    else color = color * 4.0f;
+    return color * 2.0f;
+}
+
+// ---------------------------------------------------------------- trace loop
+
+// trace_ray (main.cpp:716-761) for a stream of primary rays, as ONE loop around ONE closest-hit
+// query: radiance rays and shadow rays of different lanes share the query, so a wave stays busy
+// while its lanes are at different stages.  The reference's result is linear in the radiance of
 // the child rays, so each pending ray carries the product of the blend factors on its path:
 //   local shading      weight * (1 - refl) * (ratio if refractive else 1)
 //   refraction child   weight * (1 - refl) * (1 - ratio)
 //   reflection child   weight * refl
 // Rays deeper than max_depth are dropped (the reference recurses without bound).
+//
+// Source supplies primary rays and receives their radiance:
+//   bool next(v3 &o, v3 &d);  void done(v3 radiance);  rt_hit_record *first_hit();
 struct Pending { v3 o, d; float w; int32_t depth; };
 
-template <bool COUNT, class Stack>
-RT_HD v3 trace(const DevScene &S, v3 ro, v3 rd, int max_depth, int accel, Stack &stk, Work &wk,
-               rt_hit_record *first_hit) {
+template <bool COUNT, class Stack, class Source>
+RT_HD void trace_loop(const DevScene &S, int max_depth, int accel, Stack &stk, Work &wk, Source &src) {
     Pending pend[RT_MAX_DEPTH + 1];
     int np = 0;
+    v3 o, d;
+    if (!src.next(o, d)) return;
     v3 radiance = V3(0, 0, 0);
-    v3 o = ro, d = rd;
     float weight = 1.0f;
     int depth = 0;
     bool primary = true;
+    int light = -1;  // -1: the ray in flight is a radiance ray; >= 0: shadow ray towards that light
+    float clip = INFINITY, occl = -INFINITY, light_r = 0;
+    ShadeCtx sc;
     for (;;) {
-        if (primary) wk.rays_primary++; else wk.rays_secondary++;
         Closest c;
-        find_closest<COUNT>(S, o, d, accel, c, stk, wk);
-        Surf s;
-        if (c.object >= 0) resolve<COUNT>(S, c, o, d, s, wk);
-        if (primary && first_hit) {
-            rt_hit_record &h = *first_hit;
-            h.hit = c.object >= 0; h.object = c.object; h.from_outside = 1; h.distance = c.distance;
-            h.frag = 0; h.sub = 0;
-            for (int i = 0; i < 3; i++) { h.normal[i] = 0; h.point[i] = 0; }
-            h.uv[0] = h.uv[1] = 0;
-            if (c.object >= 0) {
-                h.frag = s.frag; h.sub = s.sub;
-                h.normal[0] = s.normal.x; h.normal[1] = s.normal.y; h.normal[2] = s.normal.z;
-                h.point[0] = s.point.x; h.point[1] = s.point.y; h.point[2] = s.point.z;
-                h.uv[0] = s.uv.x; h.uv[1] = s.uv.y;
+        find_closest<COUNT>(S, o, d, accel, clip, occl, c, stk, wk);
+        bool shade_done = false, ray_done = false;
+        if (light < 0) {
+            if (primary) wk.rays_primary++; else wk.rays_secondary++;
+            Surf s;
+            if (c.object >= 0) resolve<COUNT>(S, c, o, d, s, wk);
+            if (primary) {
+                rt_hit_record *fh = src.first_hit();
+                if (fh) fill_hit(*fh, c, s);
             }
+            primary = false;
+            if (c.object >= 0) {
+                shade_begin<COUNT>(S, s, d, sc, wk);
+                light = 0;
+                shade_done = S.n_lights == 0;
+            } else {
+                ray_done = true;
+            }
+        } else {
+            wk.rays_shadow++;
+            if (!(c.distance < light_r)) shade_light<COUNT>(S, sc, light, d, light_r, wk);
+            light++;
+            shade_done = light >= S.n_lights;
         }
-        primary = false;
-        bool have_next = false;
-        if (c.object >= 0) {
-            const rt_material &m = S.materials[s.material];
-            v3 local = phong<COUNT>(S, s, normalize(-d), accel, stk, wk);
+        if (!ray_done && !shade_done) {
+            // next shadow ray (main.cpp:650-656): from point + EPS * L towards light `light`
+            v3 lp = ld3(S.light_pos + 3 * light);
+            v3 L = normalize(lp - sc.point);
+            o = sc.point + L * kEps;
+            d = L;
+            light_r = distance(sc.point, lp);
+            occl = light_r;
+            clip = light_r * 1.001f + 1e-3f;  // |L| = 1, so the local ray parameter equals the world distance up to rounding
+            continue;
+        }
+        if (shade_done) {
+            light = -1; clip = INFINITY; occl = -INFINITY;
+            const rt_material &m = S.materials[sc.material];
+            v3 local = shade_end<COUNT>(S, sc, wk);
             float refl = m.reflectiveness, refr = m.refractiveness, ratio = m.refractive_ratio;
             float w_after_refl = refl > 0 ? weight * (1 - refl) : weight;
             float w_local = refr > 0 ? w_after_refl * ratio : w_after_refl;
             radiance = radiance + local * w_local;
             int cd = depth + 1;
-            bool deeper = cd <= max_depth;
-            v3 no = o, ndv = d;
-            float nw = 0;
+            bool deeper = cd <= max_depth, have_next = false;
             if (refr > 0 && deeper) {
-                float index = s.from_outside ? refr : 1 / refr;
-                v3 rdir = refract_dir(d, s.normal, index);
-                no = s.point + rdir * kEps; ndv = rdir; nw = w_after_refl * (1.f - ratio);
+                float index = sc.from_outside ? refr : 1 / refr;
+                v3 rdir = refract_dir(sc.d_in, sc.normal, index);
+                o = sc.point + rdir * kEps; d = rdir;
                 have_next = true;
             }
-            if (refl > 0 && s.from_outside && deeper) {
-                v3 rdir = reflect(d, s.normal);
-                v3 ro2 = s.point + rdir * kEps;
+            if (refl > 0 && sc.from_outside && deeper) {
+                v3 rdir = reflect(sc.d_in, sc.normal);
+                v3 ro2 = sc.point + rdir * kEps;
                 float rw = weight * refl;
                 if (have_next) {
                     if (np <= RT_MAX_DEPTH) { pend[np].o = ro2; pend[np].d = rdir; pend[np].w = rw; pend[np].depth = cd; np++; }
                 } else {
-                    no = ro2; ndv = rdir; nw = rw; have_next = true;
+                    o = ro2; d = rdir; weight = rw; depth = cd; have_next = true;
+                    continue;
                 }
             }
-            if (have_next) { o = no; d = ndv; weight = nw; depth = cd; }
+            if (have_next) { weight = w_after_refl * (1.f - ratio); depth = cd; continue; }
         }
-        if (!have_next) {
-            if (np == 0) break;
+        // this ray's subtree is finished: resume a pending ray, else hand the radiance over
+        if (np > 0) {
             np--;
             o = pend[np].o; d = pend[np].d; weight = pend[np].w; depth = pend[np].depth;
+            continue;
         }
+        src.done(radiance);
+        if (!src.next(o, d)) break;
+        radiance = V3(0, 0, 0); weight = 1.0f; depth = 0; primary = true;
     }
-    return radiance;
+}
+
+// a single ray (the arbitrary-ray entry points)
+struct OneRay {
+    v3 o, d, radiance;
+    rt_hit_record *hit;
+    bool taken;
+    RT_HD bool next(v3 &ro, v3 &rd) { if (taken) return false; taken = true; ro = o; rd = d; return true; }
+    RT_HD void done(v3 r) { radiance = r; }
+    RT_HD rt_hit_record *first_hit() { return hit; }
+};
+template <bool COUNT, class Stack>
+RT_HD v3 trace(const DevScene &S, v3 ro, v3 rd, int max_depth, int accel, Stack &stk, Work &wk, rt_hit_record *first_hit) {
+    OneRay src;
+    src.o = ro; src.d = rd; src.radiance = V3(0, 0, 0); src.hit = first_hit; src.taken = false;
+    trace_loop<COUNT>(S, max_depth, accel, stk, wk, src);
+    return src.radiance;
 }
 
 // ---------------------------------------------------------------- camera, tone mapping
@@ -782,23 +961,30 @@ RT_HD v3 tone_map(v3 c) {
 RT_HD uint8_t quantise(float c) { return (uint8_t)(int)(float)(255 * c); }
 
 // One pixel: all taps in order, weighted sum, normalisation (main.cpp:1243-1270)
+struct PixelTaps {
+    Camera cam;
+    int mode, grid_m, taps, i, j, k;
+    float wt;
+    v3 color;
+    RT_HD bool next(v3 &ro, v3 &rd) {
+        if (k >= taps) return false;
+        ro = V3(0, 0, 0);
+        rd = primary_dir(cam, mode, grid_m, i, j, k, wt);
+        k++;
+        return true;
+    }
+    RT_HD void done(v3 r) { color = mode == RT_MODE_REF_1SPP ? r : color + r * wt; }
+    RT_HD rt_hit_record *first_hit() { return nullptr; }
+    RT_HD v3 result() const { return mode == RT_MODE_REF_1SPP ? color : color / (mode == RT_MODE_REF_AA9 ? 16.f : (float)taps); }
+};
 template <bool COUNT, class Stack>
 RT_HD v3 render_pixel(const DevScene &S, const Camera &cam, int mode, int grid_m, int max_depth, int accel,
                       int i, int j, Stack &stk, Work &wk) {
-    int taps = taps_of(mode, grid_m);
-    if (mode == RT_MODE_REF_1SPP) {
-        float wt;
-        v3 dir = primary_dir(cam, mode, grid_m, i, j, 0, wt);
-        return trace<COUNT>(S, V3(0, 0, 0), dir, max_depth, accel, stk, wk, nullptr);
-    }
-    v3 color = V3(0, 0, 0);
-    for (int k = 0; k < taps; k++) {
-        float wt;
-        v3 dir = primary_dir(cam, mode, grid_m, i, j, k, wt);
-        v3 c = trace<COUNT>(S, V3(0, 0, 0), dir, max_depth, accel, stk, wk, nullptr);
-        color = color + c * wt;
-    }
-    return color / (mode == RT_MODE_REF_AA9 ? 16.f : (float)taps);
+    PixelTaps src;
+    src.cam = cam; src.mode = mode; src.grid_m = grid_m; src.taps = taps_of(mode, grid_m);
+    src.i = i; src.j = j; src.k = 0; src.wt = 1.0f; src.color = V3(0, 0, 0);
+    trace_loop<COUNT>(S, max_depth, accel, stk, wk, src);
+    return src.result();
 }
 
 }  // namespace rtc

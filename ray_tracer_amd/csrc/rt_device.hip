@@ -139,7 +139,7 @@ struct RenderArgs {
 // Block b renders local tile b = global tile b * world_size + rank.  Each wave owns an 8x8 pixel
 // quadrant of the 16x16 tile so that its 64 rays are spatially coherent.
 template <bool COUNT>
-__global__ __launch_bounds__(kBlock) void k_render(DevScene S, RenderArgs a, float *rgb_tiles, uint8_t *rgb8_tiles,
+__global__ __launch_bounds__(kBlock, 4) void k_render(DevScene S, RenderArgs a, float *rgb_tiles, uint8_t *rgb8_tiles,
                                                    unsigned long long *counters) {
     __shared__ int32_t lds_stack[kStackDepth * kBlock];
     LdsStack stk;
@@ -386,6 +386,13 @@ extern "C" int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *sc) {
     }
     DevTexture *d_tex;
     if ((rc = dev_alloc(ctx, &d_tex, tex.size(), tex.data()))) return rc;
+    std::vector<int32_t> plane_obj, sphere_obj, cone_obj, mesh_obj;
+    kind_to_object(sc, plane_obj, sphere_obj, cone_obj, mesh_obj);
+    int32_t *d_plane_obj, *d_sphere_obj, *d_cone_obj, *d_mesh_obj;
+    if ((rc = dev_alloc(ctx, &d_plane_obj, plane_obj.size(), plane_obj.data()))) return rc;
+    if ((rc = dev_alloc(ctx, &d_sphere_obj, sphere_obj.size(), sphere_obj.data()))) return rc;
+    if ((rc = dev_alloc(ctx, &d_cone_obj, cone_obj.size(), cone_obj.data()))) return rc;
+    if ((rc = dev_alloc(ctx, &d_mesh_obj, mesh_obj.size(), mesh_obj.data()))) return rc;
 
     // meshes: bounds, padding, gate triangles, node ranges
     ctx->n_meshes = sc->n_meshes;
@@ -410,6 +417,8 @@ extern "C" int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *sc) {
 
     DevScene &S = ctx->S;
     S.n_objects = sc->n_objects; S.n_lights = sc->n_lights;
+    S.n_planes = sc->n_planes; S.n_spheres = sc->n_spheres; S.n_cones = sc->n_cones; S.n_meshes = sc->n_meshes;
+    S.plane_obj = d_plane_obj; S.sphere_obj = d_sphere_obj; S.cone_obj = d_cone_obj; S.mesh_obj = d_mesh_obj;
     S.objects = d_objects; S.spheres = d_spheres; S.planes = d_planes; S.cones = d_cones; S.meshes = ctx->d_meshes;
     S.tri_test = ctx->d_tri_test; S.tri_key = ctx->d_tri_key; S.tri_orig = ctx->d_tri_orig;
     S.tri_nrm = d_nrm; S.tri_uv = d_uv; S.tri_material = d_tmat; S.tri_frag = ctx->d_tri_frag; S.tri_sub = ctx->d_tri_sub;

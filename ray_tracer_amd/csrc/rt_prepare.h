@@ -73,6 +73,19 @@ inline void make_gate_tris(const float *v1, const float *v2, f4 *out) {
     }
 }
 
+// object index of every plane / sphere / cone / mesh, in the order of their own arrays
+inline void kind_to_object(const rt_scene_desc *sc, std::vector<int32_t> &plane_obj, std::vector<int32_t> &sphere_obj,
+                           std::vector<int32_t> &cone_obj, std::vector<int32_t> &mesh_obj) {
+    plane_obj.assign(sc->n_planes, -1); sphere_obj.assign(sc->n_spheres, -1);
+    cone_obj.assign(sc->n_cones, -1); mesh_obj.assign(sc->n_meshes, -1);
+    for (int i = 0; i < sc->n_objects; i++) {
+        rt_object ob = sc->objects[i];
+        std::vector<int32_t> &v = ob.kind == RT_OBJ_PLANE ? plane_obj : ob.kind == RT_OBJ_SPHERE ? sphere_obj
+                                  : ob.kind == RT_OBJ_CONE ? cone_obj : mesh_obj;
+        if (v[ob.index] < 0) v[ob.index] = i;
+    }
+}
+
 // Fills the device-side mesh records (everything but device pointers), the per-mesh build data and
 // the gate triangles (36 f4 per mesh).  Returns the total number of LBVH nodes.
 inline int prepare_meshes(const rt_scene_desc *sc, std::vector<DevMesh> &meshes, std::vector<MeshBuild> &build,
@@ -111,7 +124,10 @@ inline int prepare_meshes(const rt_scene_desc *sc, std::vector<DevMesh> &meshes,
         float gmax = 0;
         for (int a = 0; a < 3; a++) gmax = std::max(gmax, std::max(std::fabs(m.box_min[a]), std::fabs(m.box_max[a])));
         float gpad = std::isfinite(gmax) ? std::max(gmax * 2e-5f, 1e-30f) : 0.0f;
-        for (int a = 0; a < 3; a++) { dm.gate_lo[a] = m.box_min[a] - gpad; dm.gate_hi[a] = m.box_max[a] + gpad; }
+        for (int a = 0; a < 3; a++) {
+            dm.gate_lo[a] = m.box_min[a] - gpad; dm.gate_hi[a] = m.box_max[a] + gpad;
+            dm.gate_in_lo[a] = m.box_min[a] + gpad; dm.gate_in_hi[a] = m.box_max[a] - gpad;
+        }
         make_gate_tris(m.box_min, m.box_max, gate.data() + 36 * (size_t)i);
     }
     return node_total;

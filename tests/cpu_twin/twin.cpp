@@ -40,6 +40,7 @@ struct Twin {
     std::vector<f4> tri_test, gate;
     std::vector<uint32_t> tri_key;
     std::vector<int32_t> tri_orig, tri_material, tri_frag, tri_sub;
+    std::vector<int32_t> plane_obj, sphere_obj, cone_obj, mesh_obj;
     std::vector<float> tri_pos, tri_nrm, tri_uv, light_pos, light_color;
     std::vector<BvhNode> nodes;
     std::vector<rt_material> materials;
@@ -106,6 +107,9 @@ void *twin_create(const rt_scene_desc *sc, char *errbuf, int errcap) {
     for (const DevMesh &m : t->meshes) gather(*t, m, nullptr);
     DevScene &S = t->S;
     S.n_objects = sc->n_objects; S.n_lights = sc->n_lights;
+    S.n_planes = sc->n_planes; S.n_spheres = sc->n_spheres; S.n_cones = sc->n_cones; S.n_meshes = sc->n_meshes;
+    kind_to_object(sc, t->plane_obj, t->sphere_obj, t->cone_obj, t->mesh_obj);
+    S.plane_obj = t->plane_obj.data(); S.sphere_obj = t->sphere_obj.data(); S.cone_obj = t->cone_obj.data(); S.mesh_obj = t->mesh_obj.data();
     S.objects = t->objects.data(); S.spheres = t->spheres.data(); S.planes = t->planes.data(); S.cones = t->cones.data();
     S.meshes = t->meshes.data(); S.tri_test = t->tri_test.data(); S.tri_key = t->tri_key.data(); S.tri_orig = t->tri_orig.data();
     S.tri_nrm = t->tri_nrm.data(); S.tri_uv = t->tri_uv.data(); S.tri_material = t->tri_material.data();
