@@ -31,6 +31,16 @@ constexpr float kMinDist = 0.01f;   // find_closest_hit threshold, main.cpp:705
 constexpr int kStackDepth = 32;     // LBVH traversal stack entries per ray
 constexpr double kPi = 3.14159265358979323846;
 
+// Scene features a kernel instantiation supports.  A scene is rendered by the leanest
+// instantiation that covers what it contains (fewer live registers, smaller code).
+enum : int {
+    F_MESH = 1,       // triangle meshes
+    F_QUADRIC = 2,    // spheres and cones
+    F_TEXTURE = 4,    // any textured material
+    F_SECONDARY = 8,  // any reflective or refractive material
+    F_ALL = 15
+};
+
 struct v2 { float x, y; };
 struct v3 { float x, y, z; };
 struct alignas(16) f4 { float x, y, z, w; };
@@ -206,14 +216,14 @@ RT_HD bool plane_hit(const rt_plane &pl, v3 ro, v3 rd, float &t) {
     t = PdotN / DdotN;  // evaluated unconditionally (no divergent exit); only used when DdotN < 0
     return (DdotN < 0) & (t > 0);
 }
-template <bool COUNT>
+template <int F, bool COUNT>
 RT_HD void plane_surface(const DevScene &S, const rt_plane &pl, v3 ro, v3 rd, float t, Surf &s, Work &wk) {
     v3 n = ld3(pl.normal), b1 = ld3(pl.b1), b2 = ld3(pl.b2);
     s.point = rd * t + ro;
     s.uv.x = dot(b1, s.point);
     s.uv.y = dot(b2, s.point);
     s.material = pl.material;
-    const DevTexture *it = image_texture_of(S, S.materials[pl.material]);
+    const DevTexture *it = (F & F_TEXTURE) ? image_texture_of(S, S.materials[pl.material]) : nullptr;
     if (it) {
         v3 tn = tex_rgb<COUNT>(*it, 1, s.uv, wk);
         tn = tn * 2.f - V3(1, 1, 1);
@@ -257,14 +267,14 @@ RT_HD bool sphere_geom(const rt_sphere &sp, v3 ro, v3 rd, QuadricHit &q) {
     return true;
 }
 // Sphere::intersect, main.cpp:153-181 (uv, normal mapping, world transform)
-template <bool COUNT>
+template <int F, bool COUNT>
 RT_HD void sphere_surface(const DevScene &S, const rt_sphere &sp, const QuadricHit &q, Surf &s, Work &wk) {
     v3 i = q.i;
     s.uv.x = (float)(((double)atan2f(i.z, i.x) + kPi) / kPi);
     s.uv.y = (float)(((double)asinf(i.y) + kPi / 2) / kPi);
     s.point = xform_point(sp.to_world, i);
     s.material = sp.material;
-    const DevTexture *it = image_texture_of(S, S.materials[sp.material]);
+    const DevTexture *it = (F & F_TEXTURE) ? image_texture_of(S, S.materials[sp.material]) : nullptr;
     v3 n;
     if (it) {
         v3 tangent = V3(sinf(s.uv.x), 0, cosf(s.uv.x));
@@ -314,12 +324,12 @@ RT_HD bool cone_geom(const rt_cone &cn, v3 ro, v3 rd, QuadricHit &q) {
     q.distance = distance(ro, xform_point(cn.to_world, q.i));
     return true;
 }
-template <bool COUNT>
+template <int F, bool COUNT>
 RT_HD void cone_surface(const DevScene &S, const rt_cone &cn, const QuadricHit &q, Surf &s, Work &wk) {
     v3 n;
     if (q.cap) {
         Surf ps;
-        plane_surface<COUNT>(S, cn.cap, q.o, q.d, q.t, ps, wk);
+        plane_surface<F, COUNT>(S, cn.cap, q.o, q.d, q.t, ps, wk);
         s.uv = ps.uv;
         n = ps.normal;
         s.point = ps.point;
@@ -461,6 +471,7 @@ RT_HD void tri_test_flat(const f4 *tt, int32_t k, uint32_t key, v3 o, v3 d, TriB
 
 constexpr int32_t kTraversalDone = 0x7fffffff;
 
+
 // Closest triangle of a mesh for a local-space ray: stack traversal of the mesh's LBVH in
 // "while-while" form -- every lane walks inner nodes until it holds a leaf (or is finished), then
 // the lanes holding leaves test their triangles together.  Near child first, far child pushed; a
@@ -595,7 +606,7 @@ struct Closest {
 RT_HD bool closer(float dist, int32_t idx, const Closest &best) {
     return (dist > kMinDist) & ((dist < best.distance) | ((dist == best.distance) & (idx < best.object)));
 }
-template <bool COUNT, class Stack>
+template <int F, bool COUNT, class Stack>
 RT_HD void find_closest(const DevScene &S, v3 ro, v3 rd, int accel, float clip, float occl, Closest &best, Stack &stk, Work &wk) {
     best.distance = INFINITY;
     best.object = -1;
@@ -609,6 +620,7 @@ RT_HD void find_closest(const DevScene &S, v3 ro, v3 rd, int accel, float clip, 
         bool ok = plane_hit(S.planes[i], ro, rd, t) & closer(t, idx, best);
         best.distance = ok ? t : best.distance; best.object = ok ? idx : best.object; best.t = ok ? t : best.t; best.k = ok ? 0 : best.k;
     }
+    if (F & F_QUADRIC)
     for (int32_t i = 0; i < S.n_spheres; i++) {
         QuadricHit q;
         if (COUNT) wk.quadric++;
@@ -618,6 +630,7 @@ RT_HD void find_closest(const DevScene &S, v3 ro, v3 rd, int accel, float clip, 
             best.distance = q.distance; best.object = idx; best.t = q.t; best.k = 0;
         }
     }
+    if (F & F_QUADRIC)
     for (int32_t i = 0; i < S.n_cones; i++) {
         QuadricHit q;
         if (COUNT) wk.quadric++;
@@ -627,6 +640,7 @@ RT_HD void find_closest(const DevScene &S, v3 ro, v3 rd, int accel, float clip, 
             best.distance = q.distance; best.object = idx; best.t = q.t; best.k = q.cap ? 1 : 0;
         }
     }
+    if (F & F_MESH)
     for (int32_t i = 0; i < S.n_meshes; i++) {
         int32_t idx = S.mesh_obj[i];
         if (idx < 0 || best.distance < occl) continue;
@@ -637,27 +651,29 @@ RT_HD void find_closest(const DevScene &S, v3 ro, v3 rd, int accel, float clip, 
     }
 }
 
-template <bool COUNT>
+template <int F, bool COUNT>
 RT_HD void resolve(const DevScene &S, const Closest &c, v3 ro, v3 rd, Surf &s, Work &wk) {
     rt_object ob = S.objects[c.object];
     if (ob.kind == RT_OBJ_PLANE) {
-        plane_surface<COUNT>(S, S.planes[ob.index], ro, rd, c.t, s, wk);
-    } else if (ob.kind == RT_OBJ_MESH) {
+        plane_surface<F, COUNT>(S, S.planes[ob.index], ro, rd, c.t, s, wk);
+    } else if ((F & F_MESH) && ob.kind == RT_OBJ_MESH) {
         mesh_surface(S, S.meshes[ob.index], ro, rd, c.t, c.k, s);
+    } else if (!(F & F_QUADRIC)) {
+        // unreachable: the scene has no object of another kind
     } else if (ob.kind == RT_OBJ_SPHERE) {
         const rt_sphere &sp = S.spheres[ob.index];
         QuadricHit q;
         q.o = xform_point(sp.to_local, ro); q.d = xform_dir(sp.to_local, rd);
         q.t = c.t; q.cap = false; q.i = q.o + q.d * c.t;
         q.from_outside = !(fabsf(q.o.x) < 1 && fabsf(q.o.y) < 1 && fabsf(q.o.z) < 1);
-        sphere_surface<COUNT>(S, sp, q, s, wk);
+        sphere_surface<F, COUNT>(S, sp, q, s, wk);
     } else {
         const rt_cone &cn = S.cones[ob.index];
         QuadricHit q;
         q.d = xform_dir(cn.to_local, rd); q.o = xform_point(cn.to_local, ro);
         q.t = c.t; q.cap = c.k != 0; q.from_outside = true;
         q.i = q.cap ? q.d * c.t + q.o : q.o + q.d * c.t;
-        cone_surface<COUNT>(S, cn, q, s, wk);
+        cone_surface<F, COUNT>(S, cn, q, s, wk);
     }
 }
 
@@ -700,7 +716,7 @@ RT_HD void intersect_object(const DevScene &S, int32_t k, v3 ro, v3 rd, int acce
     s.point = V3(0, 0, 0); s.normal = V3(0, 0, 0); s.uv.x = s.uv.y = 0;
     if (hit) {
         c.object = k;
-        resolve<COUNT>(S, c, ro, rd, s, wk);
+        resolve<F_ALL, COUNT>(S, c, ro, rd, s, wk);
     }
     fill_hit(out, c, s);
     out.from_outside = from_outside ? 1 : 0;
@@ -751,20 +767,23 @@ struct ShadeCtx {
     bool from_outside;
 };
 
-template <bool COUNT>
+template <int F, bool COUNT>
 RT_HD void shade_begin(const DevScene &S, const Surf &s, v3 d_in, ShadeCtx &sc, Work &wk) {
     const rt_material &m = S.materials[s.material];
     sc.point = s.point; sc.normal = s.normal; sc.d_in = d_in; sc.uv = s.uv;
     sc.material = s.material; sc.from_outside = s.from_outside;
     sc.color = ld3(S.ambient) * ld3(m.ambient);
-    const DevTexture *tex = m.texture >= 0 ? &S.textures[m.texture] : nullptr;
+    const DevTexture *tex = ((F & F_TEXTURE) && m.texture >= 0) ? &S.textures[m.texture] : nullptr;
     const DevTexture *img = (tex && tex->kind == RT_TEX_IMAGE) ? tex : nullptr;
     sc.dc = ld3(m.diffuse);
     if (tex) sc.dc = tex_color<COUNT>(*tex, s.uv, wk);
     sc.shininess = m.shininess;
     if (img) {
         sc.dc = sc.dc * 5.f;  // diffuse *= 5 (main.cpp:673) commutes with the NdotL factor
-        sc.shininess = (float)(.5 / pow((double)tex_rgba<COUNT>(*img, 3, s.uv, wk).x, 4.0) - .5);
+        // .5 / pow(roughness, 4) - .5 in double (main.cpp:674): r*r is exact in double, its square rounds once
+        double r2 = (double)tex_rgba<COUNT>(*img, 3, s.uv, wk).x;
+        r2 = r2 * r2;
+        sc.shininess = (float)(.5 / (r2 * r2) - .5);
     }
 }
 // one light's contribution (main.cpp:658-685); L is the normalised direction to the light
@@ -784,10 +803,10 @@ RT_HD void shade_light(const DevScene &S, ShadeCtx &sc, int l, v3 L, float r, Wo
     term = ld3(S.light_color + 3 * l) * term;
     sc.color = sc.color + term * (1.3f * inv_r * inv_r);
 }
-template <bool COUNT>
+template <int F, bool COUNT>
 RT_HD v3 shade_end(const DevScene &S, const ShadeCtx &sc, Work &wk) {
     const rt_material &m = S.materials[sc.material];
-    const DevTexture *img = image_texture_of(S, m);
+    const DevTexture *img = (F & F_TEXTURE) ? image_texture_of(S, m) : nullptr;
     v3 color = sc.color;
     if (img) color = color * tex_rgb<COUNT>(*img, 2, sc.uv, wk);
     else color = color * 4.0f;
@@ -809,9 +828,9 @@ RT_HD v3 shade_end(const DevScene &S, const ShadeCtx &sc, Work &wk) {
 //   bool next(v3 &o, v3 &d);  void done(v3 radiance);  rt_hit_record *first_hit();
 struct Pending { v3 o, d; float w; int32_t depth; };
 
-template <bool COUNT, class Stack, class Source>
+template <int F, bool COUNT, class Stack, class Source>
 RT_HD void trace_loop(const DevScene &S, int max_depth, int accel, Stack &stk, Work &wk, Source &src) {
-    Pending pend[RT_MAX_DEPTH + 1];
+    Pending pend[(F & F_SECONDARY) ? RT_MAX_DEPTH + 1 : 1];
     int np = 0;
     v3 o, d;
     if (!src.next(o, d)) return;
@@ -824,19 +843,19 @@ RT_HD void trace_loop(const DevScene &S, int max_depth, int accel, Stack &stk, W
     ShadeCtx sc;
     for (;;) {
         Closest c;
-        find_closest<COUNT>(S, o, d, accel, clip, occl, c, stk, wk);
+        find_closest<F, COUNT>(S, o, d, accel, clip, occl, c, stk, wk);
         bool shade_done = false, ray_done = false;
         if (light < 0) {
             if (primary) wk.rays_primary++; else wk.rays_secondary++;
             Surf s;
-            if (c.object >= 0) resolve<COUNT>(S, c, o, d, s, wk);
+            if (c.object >= 0) resolve<F, COUNT>(S, c, o, d, s, wk);
             if (primary) {
                 rt_hit_record *fh = src.first_hit();
                 if (fh) fill_hit(*fh, c, s);
             }
             primary = false;
             if (c.object >= 0) {
-                shade_begin<COUNT>(S, s, d, sc, wk);
+                shade_begin<F, COUNT>(S, s, d, sc, wk);
                 light = 0;
                 shade_done = S.n_lights == 0;
             } else {
@@ -862,8 +881,9 @@ RT_HD void trace_loop(const DevScene &S, int max_depth, int accel, Stack &stk, W
         if (shade_done) {
             light = -1; clip = INFINITY; occl = -INFINITY;
             const rt_material &m = S.materials[sc.material];
-            v3 local = shade_end<COUNT>(S, sc, wk);
-            float refl = m.reflectiveness, refr = m.refractiveness, ratio = m.refractive_ratio;
+            v3 local = shade_end<F, COUNT>(S, sc, wk);
+            float refl = (F & F_SECONDARY) ? m.reflectiveness : 0.0f, refr = (F & F_SECONDARY) ? m.refractiveness : 0.0f;
+            float ratio = m.refractive_ratio;
             float w_after_refl = refl > 0 ? weight * (1 - refl) : weight;
             float w_local = refr > 0 ? w_after_refl * ratio : w_after_refl;
             radiance = radiance + local * w_local;
@@ -889,7 +909,7 @@ RT_HD void trace_loop(const DevScene &S, int max_depth, int accel, Stack &stk, W
             if (have_next) { weight = w_after_refl * (1.f - ratio); depth = cd; continue; }
         }
         // this ray's subtree is finished: resume a pending ray, else hand the radiance over
-        if (np > 0) {
+        if ((F & F_SECONDARY) && np > 0) {
             np--;
             o = pend[np].o; d = pend[np].d; weight = pend[np].w; depth = pend[np].depth;
             continue;
@@ -909,11 +929,11 @@ struct OneRay {
     RT_HD void done(v3 r) { radiance = r; }
     RT_HD rt_hit_record *first_hit() { return hit; }
 };
-template <bool COUNT, class Stack>
+template <int F, bool COUNT, class Stack>
 RT_HD v3 trace(const DevScene &S, v3 ro, v3 rd, int max_depth, int accel, Stack &stk, Work &wk, rt_hit_record *first_hit) {
     OneRay src;
     src.o = ro; src.d = rd; src.radiance = V3(0, 0, 0); src.hit = first_hit; src.taken = false;
-    trace_loop<COUNT>(S, max_depth, accel, stk, wk, src);
+    trace_loop<F, COUNT>(S, max_depth, accel, stk, wk, src);
     return src.radiance;
 }
 
@@ -977,13 +997,13 @@ struct PixelTaps {
     RT_HD rt_hit_record *first_hit() { return nullptr; }
     RT_HD v3 result() const { return mode == RT_MODE_REF_1SPP ? color : color / (mode == RT_MODE_REF_AA9 ? 16.f : (float)taps); }
 };
-template <bool COUNT, class Stack>
+template <int F, bool COUNT, class Stack>
 RT_HD v3 render_pixel(const DevScene &S, const Camera &cam, int mode, int grid_m, int max_depth, int accel,
                       int i, int j, Stack &stk, Work &wk) {
     PixelTaps src;
     src.cam = cam; src.mode = mode; src.grid_m = grid_m; src.taps = taps_of(mode, grid_m);
     src.i = i; src.j = j; src.k = 0; src.wt = 1.0f; src.color = V3(0, 0, 0);
-    trace_loop<COUNT>(S, max_depth, accel, stk, wk, src);
+    trace_loop<F, COUNT>(S, max_depth, accel, stk, wk, src);
     return src.result();
 }
 

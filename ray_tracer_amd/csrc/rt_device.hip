@@ -138,7 +138,7 @@ struct RenderArgs {
 
 // Block b renders local tile b = global tile b * world_size + rank.  Each wave owns an 8x8 pixel
 // quadrant of the 16x16 tile so that its 64 rays are spatially coherent.
-template <bool COUNT>
+template <int F, bool COUNT>
 __global__ __launch_bounds__(kBlock, 4) void k_render(DevScene S, RenderArgs a, float *rgb_tiles, uint8_t *rgb8_tiles,
                                                    unsigned long long *counters) {
     __shared__ int32_t lds_stack[kStackDepth * kBlock];
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_render(DevScene S, RenderArgs a, 
     work_zero(wk);
     v3 color = V3(0, 0, 0);
     bool inside = tile < a.tiles_total && i < a.width && j < a.height;
-    if (inside) color = render_pixel<COUNT>(S, a.cam, a.mode, a.grid_m, a.max_depth, a.accel, i, j, stk, wk);
+    if (inside) color = render_pixel<F, COUNT>(S, a.cam, a.mode, a.grid_m, a.max_depth, a.accel, i, j, stk, wk);
     size_t p = ((size_t)blockIdx.x * (RT_TILE_W * RT_TILE_H) + (size_t)py * RT_TILE_W + px) * 3;
     if (rgb_tiles) { rgb_tiles[p] = color.x; rgb_tiles[p + 1] = color.y; rgb_tiles[p + 2] = color.z; }
     if (rgb8_tiles) {
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_rays(DevScene S, long long n, 
     work_zero(wk);
     if (r < n) {
         rt_hit_record h;
-        v3 c = trace<false>(S, ld3(o + 3 * r), ld3(d + 3 * r), max_depth, accel, stk, wk, hits ? &h : nullptr);
+        v3 c = trace<F_ALL, false>(S, ld3(o + 3 * r), ld3(d + 3 * r), max_depth, accel, stk, wk, hits ? &h : nullptr);
         if (hits) hits[r] = h;
         if (radiance) { radiance[3 * r] = c.x; radiance[3 * r + 1] = c.y; radiance[3 * r + 2] = c.z; }
     }
@@ -245,6 +245,7 @@ struct rt_ctx {
     DevMesh *d_meshes = nullptr;
     unsigned long long *d_counters = nullptr;
     float last_trace_ms = 0, last_build_ms = 0;
+    int features = F_ALL;
     int bvh_max_depth = 0;
 };
 
@@ -426,6 +427,7 @@ extern "C" int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *sc) {
     S.light_pos = d_lp; S.light_color = d_lc;
     for (int a = 0; a < 3; a++) S.ambient[a] = sc->ambient[a];
     RT_HIP(hipStreamSynchronize(ctx->stream));  // the caller's arrays may go away after return
+    ctx->features = scene_features(sc);
     ctx->uploaded = true;
     ctx->built = false;
     return RT_OK;
@@ -553,10 +555,15 @@ extern "C" int rt_render_shard_device(rt_ctx *ctx, const rt_render_params *p, fl
     int local_tiles = (a.tiles_total - p->rank + p->world_size - 1) / p->world_size;  // tiles t = b*W + rank < total
     if (local_tiles <= 0) return RT_OK;
     RT_HIP(hipEventRecord(ctx->ev0, ctx->stream));
-    if (p->count_work)
-        hipLaunchKernelGGL(k_render<true>, dim3(local_tiles), dim3(kBlock), 0, ctx->stream, ctx->S, a, d_rgb_tiles, d_rgb8_tiles, ctx->d_counters);
-    else
-        hipLaunchKernelGGL(k_render<false>, dim3(local_tiles), dim3(kBlock), 0, ctx->stream, ctx->S, a, d_rgb_tiles, d_rgb8_tiles, ctx->d_counters);
+    // the leanest instantiation that covers the scene's features
+    void (*kernel)(DevScene, RenderArgs, float *, uint8_t *, unsigned long long *) = k_render<F_ALL, false>;
+    int f = ctx->features;
+    if (p->count_work) kernel = k_render<F_ALL, true>;
+    else if ((f & ~F_MESH) == 0) kernel = k_render<F_MESH, false>;
+    else if ((f & ~(F_MESH | F_SECONDARY)) == 0) kernel = k_render<F_MESH | F_SECONDARY, false>;
+    else if ((f & ~(F_QUADRIC | F_SECONDARY)) == 0) kernel = k_render<F_QUADRIC | F_SECONDARY, false>;
+    else if ((f & ~(F_MESH | F_TEXTURE | F_SECONDARY)) == 0) kernel = k_render<F_MESH | F_TEXTURE | F_SECONDARY, false>;
+    hipLaunchKernelGGL(kernel, dim3(local_tiles), dim3(kBlock), 0, ctx->stream, ctx->S, a, d_rgb_tiles, d_rgb8_tiles, ctx->d_counters);
     RT_HIP(hipGetLastError());
     RT_HIP(hipEventRecord(ctx->ev1, ctx->stream));
     return RT_OK;

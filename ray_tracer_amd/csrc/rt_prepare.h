@@ -73,6 +73,22 @@ inline void make_gate_tris(const float *v1, const float *v2, f4 *out) {
     }
 }
 
+// which kernel features (F_*) a scene needs
+inline int scene_features(const rt_scene_desc *sc) {
+    int f = 0;
+    for (int i = 0; i < sc->n_objects; i++) {
+        int k = sc->objects[i].kind;
+        if (k == RT_OBJ_MESH) f |= F_MESH;
+        if (k == RT_OBJ_SPHERE || k == RT_OBJ_CONE) f |= F_QUADRIC;
+    }
+    for (int i = 0; i < sc->n_materials; i++) {
+        const rt_material &m = sc->materials[i];
+        if (m.texture >= 0) f |= F_TEXTURE;
+        if (m.reflectiveness > 0 || m.refractiveness > 0) f |= F_SECONDARY;
+    }
+    return f;
+}
+
 // object index of every plane / sphere / cone / mesh, in the order of their own arrays
 inline void kind_to_object(const rt_scene_desc *sc, std::vector<int32_t> &plane_obj, std::vector<int32_t> &sphere_obj,
                            std::vector<int32_t> &cone_obj, std::vector<int32_t> &mesh_obj) {

@@ -163,7 +163,7 @@ void twin_trace_rays(void *h, int64_t n, const float *o, const float *d, int max
         Work wk;
         work_zero(wk);
         rt_hit_record hr;
-        v3 c = trace<false>(t->S, ld3(o + 3 * r), ld3(d + 3 * r), max_depth, accel, stk, wk, hits ? &hr : nullptr);
+        v3 c = trace<F_ALL, false>(t->S, ld3(o + 3 * r), ld3(d + 3 * r), max_depth, accel, stk, wk, hits ? &hr : nullptr);
         if (hits) hits[r] = hr;
         if (radiance) { radiance[3 * r] = c.x; radiance[3 * r + 1] = c.y; radiance[3 * r + 2] = c.z; }
         ms = std::max(ms, stk.max_sp);
@@ -194,7 +194,7 @@ void twin_render(void *h, const rt_render_params *p, int x0, int y0, int x1, int
             VecStack stk;
             Work wk;
             work_zero(wk);
-            v3 c = render_pixel<true>(t->S, cam, p->mode, p->grid_m, p->max_depth, p->accel, i, j, stk, wk);
+            v3 c = render_pixel<F_ALL, true>(t->S, cam, p->mode, p->grid_m, p->max_depth, p->accel, i, j, stk, wk);
             size_t q = 3 * ((size_t)j * p->width + i);
             if (rgb) { rgb[q] = c.x; rgb[q + 1] = c.y; rgb[q + 2] = c.z; }
             if (rgb8) { v3 tm = tone_map(c); rgb8[q] = quantise(tm.x); rgb8[q + 1] = quantise(tm.y); rgb8[q + 2] = quantise(tm.z); }
