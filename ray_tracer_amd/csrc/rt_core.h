@@ -100,12 +100,21 @@ struct BvhNode {  // 64 bytes: both children's boxes, then the children
 };
 
 struct DevMesh {
+    float world_lo[3], world_hi[3];  // padded world-space bounds of the (gate box of the) mesh: first, cheapest rejection
     float to_local[12], to_world[12], normal_mat[12], box_to_local[12];
     float gate_lo[3], gate_hi[3];        // padded Box bounds for the conservative pre-test
     float gate_in_lo[3], gate_in_hi[3];  // shrunken Box bounds: an origin inside sees only back faces
     int32_t tri_offset, tri_count, boxed, node_offset;
     int32_t gate_tri_offset;  // first of this mesh's 12 gate triangles in DevScene::gate_tri
-    int32_t pad[3];
+    int32_t same_xform;       // the Box and the mesh share one transformation (always so in the reference's scenes)
+    int32_t pad[2];
+};
+
+// What the plane test of find_closest reads, one 32-byte record per plane of the object list.
+struct PlaneRec {
+    float n[3], p[3];
+    int32_t object;  // index in the object list
+    int32_t plane;   // index in the plane array
 };
 
 struct DevTexture {
@@ -120,6 +129,8 @@ struct DevScene {
     int32_t n_planes, n_spheres, n_cones, n_meshes;
     const rt_object *objects;
     const int32_t *plane_obj, *sphere_obj, *cone_obj, *mesh_obj;  // index of each plane / ... in `objects`
+    int32_t n_plane_recs, pad0;
+    const PlaneRec *plane_recs;
     const rt_sphere *spheres;
     const rt_plane *planes;
     const rt_cone *cones;
@@ -433,7 +444,16 @@ RT_HD bool slab(const float *lo, const float *hi, v3 o, v3 inv, float tmax, floa
 }
 
 RT_HD float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
-RT_HD float safe_rcp(float x) { return fabsf(x) >= 1e-30f ? 1.0f / x : copysignf(1e30f, x); }
+// Reciprocal for the conservative box tests only (never for a hit decision): 1-ulp hardware rcp on
+// the GPU; a zero component becomes a huge finite value so that the fused slab test cannot produce
+// inf - inf.
+RT_HD float safe_rcp(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return fabsf(x) >= 1e-30f ? __builtin_amdgcn_rcpf(x) : copysignf(1e30f, x);
+#else
+    return fabsf(x) >= 1e-30f ? 1.0f / x : copysignf(1e30f, x);
+#endif
+}
 
 // The same test in fused form for the traversal loop: t = bound * inv - o * inv.  The boxes of the
 // tree are padded by ~100 ulps of the mesh's largest coordinate, far more than the rounding
@@ -532,23 +552,27 @@ struct MeshHit {
 // first and the 12 exact triangle tests run only for rays that found a triangle (the gate is a
 // conjunct of the result, so the order does not matter).
 template <bool COUNT, class Stack>
-RT_HD bool mesh_geom(const DevScene &S, const DevMesh &m, v3 ro, v3 rd, int accel, float clip, MeshHit &mh, Stack &stk, Work &wk) {
+RT_HD bool mesh_geom(const DevScene &S, const DevMesh &m, v3 ro, v3 rd, v3 winv, v3 woi, int accel, float clip, MeshHit &mh, Stack &stk, Work &wk) {
     if (m.tri_count <= 0) return false;
+    float tn;
+    if (COUNT) wk.box++;
+    if (!slab_fused(m.world_lo[0], m.world_lo[1], m.world_lo[2], m.world_hi[0], m.world_hi[1], m.world_hi[2], winv, woi, INFINITY, tn)) return false;
     if (has_nan(ro) || has_nan(rd)) return false;  // every triangle test fails on NaN inputs
-    v3 bo = ro, bd = rd;
+    v3 d = xform_dir(m.to_local, rd);
+    v3 o = xform_point(m.to_local, ro);
+    v3 bo = o, bd = d;
     if (m.boxed) {
-        bd = xform_dir(m.box_to_local, rd);
-        bo = xform_point(m.box_to_local, ro);
-        v3 binv = V3(1.0f / bd.x, 1.0f / bd.y, 1.0f / bd.z);
-        float tn;
+        if (!m.same_xform) {
+            bd = xform_dir(m.box_to_local, rd);
+            bo = xform_point(m.box_to_local, ro);
+        }
+        v3 binv = V3(safe_rcp(bd.x), safe_rcp(bd.y), safe_rcp(bd.z));
         if (COUNT) wk.box++;
-        if (!slab(m.gate_lo, m.gate_hi, bo, binv, INFINITY, tn)) return false;
+        if (!slab_fused(m.gate_lo[0], m.gate_lo[1], m.gate_lo[2], m.gate_hi[0], m.gate_hi[1], m.gate_hi[2], binv, bo * binv, INFINITY, tn)) return false;
         if (bo.x > m.gate_in_lo[0] && bo.x < m.gate_in_hi[0] && bo.y > m.gate_in_lo[1] && bo.y < m.gate_in_hi[1] &&
             bo.z > m.gate_in_lo[2] && bo.z < m.gate_in_hi[2])
             return false;
     }
-    v3 d = xform_dir(m.to_local, rd);
-    v3 o = xform_point(m.to_local, ro);
     TriBest best;
     best.t = clip; best.k = -1; best.key = 0xffffffffu;
     if (accel == RT_ACCEL_BRUTE) {
@@ -561,6 +585,10 @@ RT_HD bool mesh_geom(const DevScene &S, const DevMesh &m, v3 ro, v3 rd, int acce
     if (best.k < 0) return false;
     if (m.boxed) {
         if (COUNT) wk.gate++;
+        if (!m.same_xform) {  // recomputed rather than kept live across the traversal
+            bd = xform_dir(m.box_to_local, rd);
+            bo = xform_point(m.box_to_local, ro);
+        }
         const f4 *gt = S.gate_tri + 3 * (size_t)m.gate_tri_offset;
         bool any = false;
         for (int i = 0; i < 12; i++) any = any || tri_hits(gt, i, bo, bd);
@@ -612,13 +640,21 @@ RT_HD void find_closest(const DevScene &S, v3 ro, v3 rd, int accel, float clip, 
     best.object = -1;
     best.t = 0;
     best.k = 0;
-    for (int32_t i = 0; i < S.n_planes; i++) {
-        float t;
-        if (COUNT) wk.plane++;
-        int32_t idx = S.plane_obj[i];
-        if (idx < 0) continue;  // not in the object list
-        bool ok = plane_hit(S.planes[i], ro, rd, t) & closer(t, idx, best);
-        best.distance = ok ? t : best.distance; best.object = ok ? idx : best.object; best.t = ok ? t : best.t; best.k = ok ? 0 : best.k;
+    // planes: the next record is loaded while the current one is tested
+    if (S.n_plane_recs > 0) {
+        PlaneRec cur = S.plane_recs[0];
+        for (int32_t i = 0; i < S.n_plane_recs; i++) {
+            PlaneRec nxt = S.plane_recs[i + 1 < S.n_plane_recs ? i + 1 : i];
+            if (COUNT) wk.plane++;
+            // Plane::intersect, main.cpp:222-237; the quotient is formed unconditionally (no divergent exit)
+            v3 n = ld3(cur.n);
+            float DdotN = dot(rd, n);
+            float PdotN = dot(ld3(cur.p) - ro, n);
+            float t = PdotN / DdotN;
+            bool ok = (DdotN < 0) & (t > 0) & closer(t, cur.object, best);
+            best.distance = ok ? t : best.distance; best.object = ok ? cur.object : best.object; best.t = ok ? t : best.t; best.k = ok ? 0 : best.k;
+            cur = nxt;
+        }
     }
     if (F & F_QUADRIC)
     for (int32_t i = 0; i < S.n_spheres; i++) {
@@ -640,14 +676,17 @@ RT_HD void find_closest(const DevScene &S, v3 ro, v3 rd, int accel, float clip, 
             best.distance = q.distance; best.object = idx; best.t = q.t; best.k = q.cap ? 1 : 0;
         }
     }
-    if (F & F_MESH)
+    if ((F & F_MESH) && S.n_meshes > 0) {
+    v3 winv = V3(safe_rcp(rd.x), safe_rcp(rd.y), safe_rcp(rd.z));
+    v3 woi = ro * winv;
     for (int32_t i = 0; i < S.n_meshes; i++) {
         int32_t idx = S.mesh_obj[i];
         if (idx < 0 || best.distance < occl) continue;
         MeshHit mh;
-        if (mesh_geom<COUNT>(S, S.meshes[i], ro, rd, accel, clip, mh, stk, wk) && mh.from_outside && closer(mh.distance, idx, best)) {
+        if (mesh_geom<COUNT>(S, S.meshes[i], ro, rd, winv, woi, accel, clip, mh, stk, wk) && mh.from_outside && closer(mh.distance, idx, best)) {
             best.distance = mh.distance; best.object = idx; best.t = mh.t; best.k = mh.k;
         }
+    }
     }
 }
 
@@ -704,7 +743,8 @@ RT_HD void intersect_object(const DevScene &S, int32_t k, v3 ro, v3 rd, int acce
         c.t = t; c.distance = t;
     } else if (ob.kind == RT_OBJ_MESH) {
         MeshHit mh;
-        hit = mesh_geom<COUNT>(S, S.meshes[ob.index], ro, rd, accel, INFINITY, mh, stk, wk);
+        v3 winv = V3(safe_rcp(rd.x), safe_rcp(rd.y), safe_rcp(rd.z));
+        hit = mesh_geom<COUNT>(S, S.meshes[ob.index], ro, rd, winv, ro * winv, accel, INFINITY, mh, stk, wk);
         if (hit) { c.t = mh.t; c.k = mh.k; c.distance = mh.distance; from_outside = mh.from_outside; }
     } else {
         QuadricHit q;

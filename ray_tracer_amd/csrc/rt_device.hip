@@ -394,6 +394,10 @@ extern "C" int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *sc) {
     if ((rc = dev_alloc(ctx, &d_sphere_obj, sphere_obj.size(), sphere_obj.data()))) return rc;
     if ((rc = dev_alloc(ctx, &d_cone_obj, cone_obj.size(), cone_obj.data()))) return rc;
     if ((rc = dev_alloc(ctx, &d_mesh_obj, mesh_obj.size(), mesh_obj.data()))) return rc;
+    std::vector<PlaneRec> plane_recs;
+    make_plane_recs(sc, plane_obj, plane_recs);
+    PlaneRec *d_plane_recs;
+    if ((rc = dev_alloc(ctx, &d_plane_recs, plane_recs.size(), plane_recs.data()))) return rc;
 
     // meshes: bounds, padding, gate triangles, node ranges
     ctx->n_meshes = sc->n_meshes;
@@ -419,6 +423,7 @@ extern "C" int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *sc) {
     DevScene &S = ctx->S;
     S.n_objects = sc->n_objects; S.n_lights = sc->n_lights;
     S.n_planes = sc->n_planes; S.n_spheres = sc->n_spheres; S.n_cones = sc->n_cones; S.n_meshes = sc->n_meshes;
+    S.n_plane_recs = (int32_t)plane_recs.size(); S.pad0 = 0; S.plane_recs = d_plane_recs;
     S.plane_obj = d_plane_obj; S.sphere_obj = d_sphere_obj; S.cone_obj = d_cone_obj; S.mesh_obj = d_mesh_obj;
     S.objects = d_objects; S.spheres = d_spheres; S.planes = d_planes; S.cones = d_cones; S.meshes = ctx->d_meshes;
     S.tri_test = ctx->d_tri_test; S.tri_key = ctx->d_tri_key; S.tri_orig = ctx->d_tri_orig;

@@ -59,6 +59,23 @@ inline std::string validate_scene(const rt_scene_desc *sc) {
     return "";
 }
 
+// inverse of an affine map stored as four 3-row columns, in double precision; false if singular
+inline bool invert_affine(const float *m, double *out) {
+    double a[9];
+    for (int i = 0; i < 9; i++) a[i] = m[i];  // columns c0 c1 c2
+    double c00 = a[4] * a[8] - a[7] * a[5], c01 = a[7] * a[2] - a[1] * a[8], c02 = a[1] * a[5] - a[4] * a[2];
+    double det = a[0] * c00 + a[3] * c01 + a[6] * c02;
+    if (!(std::fabs(det) > 0) || !std::isfinite(det)) return false;
+    double id = 1.0 / det;
+    // inverse of the 3x3 block, stored by columns
+    out[0] = c00 * id; out[1] = c01 * id; out[2] = c02 * id;
+    out[3] = (a[6] * a[5] - a[3] * a[8]) * id; out[4] = (a[0] * a[8] - a[6] * a[2]) * id; out[5] = (a[3] * a[2] - a[0] * a[5]) * id;
+    out[6] = (a[3] * a[7] - a[6] * a[4]) * id; out[7] = (a[6] * a[1] - a[0] * a[7]) * id; out[8] = (a[0] * a[4] - a[3] * a[1]) * id;
+    for (int r = 0; r < 3; r++) out[9 + r] = -(out[r] * m[9] + out[3 + r] * m[10] + out[6 + r] * m[11]);
+    for (int i = 0; i < 12; i++) if (!std::isfinite(out[i])) return false;
+    return true;
+}
+
 inline void make_gate_tris(const float *v1, const float *v2, f4 *out) {
     float A[3] = {v1[0], v1[1], v1[2]}, B[3] = {v2[0], v1[1], v1[2]}, C[3] = {v2[0], v2[1], v1[2]},
           D[3] = {v1[0], v2[1], v1[2]}, G[3] = {v2[0], v2[1], v2[2]}, E[3] = {v1[0], v1[1], v2[2]},
@@ -120,7 +137,7 @@ inline int prepare_meshes(const rt_scene_desc *sc, std::vector<DevMesh> &meshes,
         std::memcpy(dm.box_to_local, m.box_to_local, sizeof dm.box_to_local);
         dm.tri_offset = m.tri_offset; dm.tri_count = m.tri_count; dm.boxed = m.boxed;
         dm.node_offset = node_total; dm.gate_tri_offset = 12 * i;
-        dm.pad[0] = dm.pad[1] = dm.pad[2] = 0;
+        dm.pad[0] = dm.pad[1] = 0;
         mb.node_offset = node_total;
         node_total += std::max(m.tri_count - 1, 0);
         float maxabs = 0;
@@ -145,8 +162,44 @@ inline int prepare_meshes(const rt_scene_desc *sc, std::vector<DevMesh> &meshes,
             dm.gate_in_lo[a] = m.box_min[a] + gpad; dm.gate_in_hi[a] = m.box_max[a] - gpad;
         }
         make_gate_tris(m.box_min, m.box_max, gate.data() + 36 * (size_t)i);
+        dm.same_xform = std::memcmp(m.box_to_local, m.to_local, sizeof m.to_local) == 0 ? 1 : 0;
+        dm.pad[0] = dm.pad[1] = 0;
+        // World-space bounds for the first rejection test: the padded gate box (boxed meshes) or the
+        // padded vertex bounds, mapped to world space in double precision and padded again.
+        double lo[3], hi[3], M[12];
+        for (int a = 0; a < 3; a++) { lo[a] = m.boxed ? dm.gate_lo[a] : mb.lo[a] - mb.pad; hi[a] = m.boxed ? dm.gate_hi[a] : mb.hi[a] + mb.pad; }
+        bool have = m.boxed ? invert_affine(m.box_to_local, M) : true;
+        if (!m.boxed) for (int a = 0; a < 12; a++) M[a] = m.to_world[a];
+        double wlo[3] = {INFINITY, INFINITY, INFINITY}, whi[3] = {-INFINITY, -INFINITY, -INFINITY}, wmax = 0;
+        for (int c = 0; c < 8 && have; c++) {
+            double x = (c & 1) ? hi[0] : lo[0], y = (c & 2) ? hi[1] : lo[1], z = (c & 4) ? hi[2] : lo[2];
+            for (int a = 0; a < 3; a++) {
+                double w = M[a] * x + M[3 + a] * y + M[6 + a] * z + M[9 + a];
+                if (!(w == w)) have = false;
+                wlo[a] = std::min(wlo[a], w); whi[a] = std::max(whi[a], w); wmax = std::max(wmax, std::fabs(w));
+            }
+        }
+        for (int a = 0; a < 3; a++) {
+            bool ok = have && std::isfinite(wlo[a]) && std::isfinite(whi[a]);
+            double wp = wmax * 1e-4 + 1e-30;
+            dm.world_lo[a] = ok ? (float)(wlo[a] - wp) : -INFINITY;  // unbounded when the bounds cannot be trusted
+            dm.world_hi[a] = ok ? (float)(whi[a] + wp) : INFINITY;
+        }
     }
     return node_total;
+}
+
+// the plane records find_closest walks: planes that occur in the object list, in plane order
+inline void make_plane_recs(const rt_scene_desc *sc, const std::vector<int32_t> &plane_obj, std::vector<PlaneRec> &recs) {
+    recs.clear();
+    for (int i = 0; i < sc->n_planes; i++) {
+        if (plane_obj[i] < 0) continue;
+        PlaneRec r;
+        for (int a = 0; a < 3; a++) { r.n[a] = sc->planes[i].normal[a]; r.p[a] = sc->planes[i].point[a]; }
+        r.object = plane_obj[i];
+        r.plane = i;
+        recs.push_back(r);
+    }
 }
 
 }  // namespace rtc
