@@ -44,6 +44,7 @@ enum : int {
 struct v2 { float x, y; };
 struct v3 { float x, y, z; };
 struct alignas(16) f4 { float x, y, z, w; };
+struct alignas(16) u4 { uint32_t x, y, z, w; };
 
 RT_HD v3 V3(float x, float y, float z) { v3 r; r.x = x; r.y = y; r.z = z; return r; }
 RT_HD v3 ld3(const float *p) { return V3(p[0], p[1], p[2]); }
@@ -92,10 +93,19 @@ RT_HD float clamp01(float x) { float m = (x < 0.0f) ? 0.0f : x; return (1.0f < m
 
 // ---------------------------------------------------------------- device-side scene
 
-struct BvhNode {  // 64 bytes: both children's boxes, then the children
+// LBVH node, 32 bytes (two 16-byte loads): the boxes of both children as 16-bit grid coordinates
+// inside the mesh's padded bounds (q = lo0.xyz hi0.xyz lo1.xyz hi1.xyz; lower bounds rounded down,
+// upper bounds up), then the children.  Small nodes matter because a traversal step is one scattered
+// load per lane: its cost is cache-line lookups, not arithmetic.
+struct BvhNode {
+    uint16_t q[12];
+    int32_t c0, c1;  // >= 0: internal node index (mesh-relative); < 0: ~c = sorted triangle position
+};
+// the same node with float boxes (build-time temporary and debug read-back)
+struct BvhNodeF {
     float lo0[3], hi0[3];
     float lo1[3], hi1[3];
-    int32_t c0, c1;  // >= 0: internal node index (mesh-relative); < 0: ~c = sorted triangle position
+    int32_t c0, c1;
     int32_t pad0, pad1;
 };
 
@@ -108,6 +118,7 @@ struct DevMesh {
     int32_t gate_tri_offset;  // first of this mesh's 12 gate triangles in DevScene::gate_tri
     int32_t same_xform;       // the Box and the mesh share one transformation (always so in the reference's scenes)
     int32_t pad[2];
+    float qbase[3], qscale[3];  // node grid: coordinate = qbase + q * qscale
 };
 
 // What the plane test of find_closest reads, one 32-byte record per plane of the object list.
@@ -506,18 +517,23 @@ RT_HD void bvh_closest(const DevScene &S, const DevMesh &m, v3 o, v3 d, TriBest 
     // A zero direction component would give inf - inf = NaN in the fused slab test; a huge finite
     // reciprocal keeps the sign logic (the ray then counts as parallel to that slab).
     v3 inv = V3(safe_rcp(d.x), safe_rcp(d.y), safe_rcp(d.z));
-    v3 oi = o * inv;
+    // grid coordinates are decoded inside the slab test: t = (qbase + q*qscale - o) * inv
+    //                                                      = q * (qscale*inv) - (o - qbase)*inv
+    v3 sinv = V3(m.qscale[0], m.qscale[1], m.qscale[2]) * inv;
+    v3 oi = (o - V3(m.qbase[0], m.qbase[1], m.qbase[2])) * inv;
     stk.reset();
     int32_t cur = m.tri_count == 1 ? ~0 : 0;
     while (cur != kTraversalDone) {
         while (cur >= 0 && cur != kTraversalDone) {
-            const f4 *np = reinterpret_cast<const f4 *>(nodes + cur);
-            f4 a = np[0], b = np[1], c = np[2], e = np[3];
+            const u4 *np = reinterpret_cast<const u4 *>(nodes + cur);
+            u4 a = np[0], b = np[1];
             if (COUNT) wk.box += 2;
             float n0, n1;
-            bool h0 = slab_fused(a.x, a.y, a.z, a.w, b.x, b.y, inv, oi, best.t, n0);
-            bool h1 = slab_fused(b.z, b.w, c.x, c.y, c.z, c.w, inv, oi, best.t, n1);
-            int32_t c0 = f2i(e.x), c1 = f2i(e.y);
+            bool h0 = slab_fused((float)(a.x & 0xffffu), (float)(a.x >> 16), (float)(a.y & 0xffffu), (float)(a.y >> 16),
+                                 (float)(a.z & 0xffffu), (float)(a.z >> 16), sinv, oi, best.t, n0);
+            bool h1 = slab_fused((float)(a.w & 0xffffu), (float)(a.w >> 16), (float)(b.x & 0xffffu), (float)(b.x >> 16),
+                                 (float)(b.y & 0xffffu), (float)(b.y >> 16), sinv, oi, best.t, n1);
+            int32_t c0 = (int32_t)b.z, c1 = (int32_t)b.w;
             bool second_first = h1 & (!h0 | (n1 < n0));
             int32_t nearc = second_first ? c1 : c0, farc = second_first ? c0 : c1;
             if (h0 & h1) stk.push(farc);
@@ -640,21 +656,18 @@ RT_HD void find_closest(const DevScene &S, v3 ro, v3 rd, int accel, float clip, 
     best.object = -1;
     best.t = 0;
     best.k = 0;
-    // planes: the next record is loaded while the current one is tested
-    if (S.n_plane_recs > 0) {
-        PlaneRec cur = S.plane_recs[0];
-        for (int32_t i = 0; i < S.n_plane_recs; i++) {
-            PlaneRec nxt = S.plane_recs[i + 1 < S.n_plane_recs ? i + 1 : i];
-            if (COUNT) wk.plane++;
-            // Plane::intersect, main.cpp:222-237; the quotient is formed unconditionally (no divergent exit)
-            v3 n = ld3(cur.n);
-            float DdotN = dot(rd, n);
-            float PdotN = dot(ld3(cur.p) - ro, n);
-            float t = PdotN / DdotN;
-            bool ok = (DdotN < 0) & (t > 0) & closer(t, cur.object, best);
-            best.distance = ok ? t : best.distance; best.object = ok ? cur.object : best.object; best.t = ok ? t : best.t; best.k = ok ? 0 : best.k;
-            cur = nxt;
-        }
+    // planes (Plane::intersect, main.cpp:222-237); the quotient is formed unconditionally so that
+    // there is no divergent exit
+    for (int32_t i = 0; i < S.n_plane_recs; i++) {
+        const PlaneRec &rec = S.plane_recs[i];
+        if (COUNT) wk.plane++;
+        v3 n = ld3(rec.n);
+        float DdotN = dot(rd, n);
+        float PdotN = dot(ld3(rec.p) - ro, n);
+        float t = PdotN / DdotN;
+        int32_t idx = rec.object;
+        bool ok = (DdotN < 0) & (t > 0) & closer(t, idx, best);
+        best.distance = ok ? t : best.distance; best.object = ok ? idx : best.object; best.t = ok ? t : best.t; best.k = ok ? 0 : best.k;
     }
     if (F & F_QUADRIC)
     for (int32_t i = 0; i < S.n_spheres; i++) {

@@ -107,7 +107,7 @@ __global__ void k_children(const unsigned long long *keys, int n, int32_t *c0, i
 // so a workgroup barrier is enough to order a pass after the previous one.
 __global__ __launch_bounds__(1024) void k_fit(int n, const int32_t *c0s, const int32_t *c1s, const f4 *tt, float pad,
                                               int32_t *done_pass, float *node_lo, float *node_hi, int32_t *height,
-                                              BvhNode *nodes, int32_t *root_height) {
+                                              const DevMesh *mesh, BvhNode *nodes, int32_t *root_height) {
     __shared__ int s_left;
     int n_int = n - 1;
     for (int i = threadIdx.x; i < n_int; i += blockDim.x) done_pass[i] = 0;
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(1024) void k_fit(int n, const int32_t *c0s, const i
         __syncthreads();
         int left = 0;
         for (int i = threadIdx.x; i < n_int; i += blockDim.x)
-            if (lbvh_fit_node(i, pass, c0s, c1s, tt, pad, done_pass, node_lo, node_hi, height, nodes) == 2) left++;
+            if (lbvh_fit_node(i, pass, c0s, c1s, tt, pad, done_pass, node_lo, node_hi, height, mesh->qbase, mesh->qscale, nodes) == 2) left++;
         if (left) atomicAdd(&s_left, left);
         __threadfence_block();
         __syncthreads();
@@ -491,7 +491,7 @@ extern "C" int rt_build_accel(rt_ctx *ctx) {
             hipLaunchKernelGGL(k_children, dim3((n + 255) / 256), blk, 0, ctx->stream, d_keys, n, d_c0, d_c1);
             hipLaunchKernelGGL(k_fit, dim3(1), dim3(1024), 0, ctx->stream, n, d_c0, d_c1,
                                ctx->d_tri_test + 3 * (size_t)m.tri_offset, ctx->mesh_build[i].pad, d_done, d_lo, d_hi, d_height,
-                               ctx->d_nodes + m.node_offset, d_root + i);
+                               ctx->d_meshes + i, ctx->d_nodes + m.node_offset, d_root + i);
         }
     }
     (void)hipEventRecord(ctx->ev1, ctx->stream);
@@ -737,7 +737,11 @@ extern "C" int rt_debug_copy_bvh(rt_ctx *ctx, int32_t mesh, float *nodes, int32_
     int nn = ctx->built ? std::max(m.tri_count - 1, 0) : 0;
     if (n_nodes) *n_nodes = nn;
     if (n_tris) *n_tris = m.tri_count;
-    if (nodes && nn) RT_HIP(hipMemcpy(nodes, ctx->d_nodes + m.node_offset, (size_t)nn * sizeof(BvhNode), hipMemcpyDeviceToHost));
+    if (nodes && nn) {
+        std::vector<BvhNode> q(nn);
+        RT_HIP(hipMemcpy(q.data(), ctx->d_nodes + m.node_offset, (size_t)nn * sizeof(BvhNode), hipMemcpyDeviceToHost));
+        for (int i = 0; i < nn; i++) dequantise_node(q[i], m.qbase, m.qscale, reinterpret_cast<BvhNodeF *>(nodes)[i]);
+    }
     if (order && m.tri_count) RT_HIP(hipMemcpy(order, ctx->d_tri_orig + m.tri_offset, (size_t)m.tri_count * sizeof(int32_t), hipMemcpyDeviceToHost));
     return RT_OK;
 }

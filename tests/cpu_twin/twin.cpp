@@ -146,7 +146,7 @@ int twin_build_accel(void *h) {
             int left = 0;
             for (int i = 0; i < n - 1; i++)
                 if (lbvh_fit_node(i, pass, c0.data(), c1.data(), tt, t->build[mi].pad, done.data(), lo.data(), hi.data(), height.data(),
-                                  &t->nodes[m.node_offset]) == 2)
+                                  m.qbase, m.qscale, &t->nodes[m.node_offset]) == 2)
                     left++;
             if (!left) break;
         }
@@ -211,7 +211,7 @@ int twin_copy_bvh(void *h, int mesh, float *nodes, int32_t *order) {
     Twin *t = static_cast<Twin *>(h);
     const DevMesh &m = t->meshes[mesh];
     int nn = std::max(m.tri_count - 1, 0);
-    if (nodes && nn) std::memcpy(nodes, &t->nodes[m.node_offset], (size_t)nn * sizeof(BvhNode));
+    for (int i = 0; nodes && i < nn; i++) dequantise_node(t->nodes[m.node_offset + i], m.qbase, m.qscale, reinterpret_cast<BvhNodeF *>(nodes)[i]);
     if (order) std::memcpy(order, &t->tri_orig[m.tri_offset], (size_t)m.tri_count * sizeof(int32_t));
     return nn;
 }
