@@ -28,7 +28,7 @@ namespace rtc {
 
 constexpr float kEps = 0.0001f;     // EPS, main.cpp:23
 constexpr float kMinDist = 0.01f;   // find_closest_hit threshold, main.cpp:705
-constexpr int kStackDepth = 32;     // LBVH traversal stack entries per ray
+constexpr int kStackDepth = 48;     // LBVH traversal stack entries per wave (a tree may be this high)
 constexpr double kPi = 3.14159265358979323846;
 
 // Scene features a kernel instantiation supports.  A scene is rendered by the leanest
@@ -72,6 +72,35 @@ RT_HD int32_t f2i(float f) {
     int32_t i; __builtin_memcpy(&i, &f, 4); return i;
 #endif
 }
+// ---- wave-level primitives (a "wave" is one lane in the host build)
+RT_HD uint64_t wave_ballot(bool p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __ballot(p);
+#else
+    return p ? 1ull : 0ull;
+#endif
+}
+RT_HD int32_t wave_uniform(int32_t v) {  // the value of the first active lane, as a scalar
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_readfirstlane(v);
+#else
+    return v;
+#endif
+}
+RT_HD int wave_lane() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (int)__lane_id();
+#else
+    return 0;
+#endif
+}
+RT_HD int popc64(uint64_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __popcll(x);
+#else
+    return __builtin_popcountll(x);
+#endif
+}
 RT_HD bool has_nan(v3 a) { return !(a.x == a.x) || !(a.y == a.y) || !(a.z == a.z); }
 
 // mat4 * vec4 of glm/detail/type_mat4x4.inl:561-572 on a matrix stored as four 3-row columns:
@@ -93,19 +122,13 @@ RT_HD float clamp01(float x) { float m = (x < 0.0f) ? 0.0f : x; return (1.0f < m
 
 // ---------------------------------------------------------------- device-side scene
 
-// LBVH node, 32 bytes (two 16-byte loads): the boxes of both children as 16-bit grid coordinates
-// inside the mesh's padded bounds (q = lo0.xyz hi0.xyz lo1.xyz hi1.xyz; lower bounds rounded down,
-// upper bounds up), then the children.  Small nodes matter because a traversal step is one scattered
-// load per lane: its cost is cache-line lookups, not arithmetic.
+// LBVH node, 64 bytes: the boxes of both children, then the children.  In the packet traversal the
+// node index is wave-uniform, so a node is fetched with ONE scalar load into SGPRs and its twelve
+// bounds feed the per-lane slab tests as scalar operands.
 struct BvhNode {
-    uint16_t q[12];
-    int32_t c0, c1;  // >= 0: internal node index (mesh-relative); < 0: ~c = sorted triangle position
-};
-// the same node with float boxes (build-time temporary and debug read-back)
-struct BvhNodeF {
     float lo0[3], hi0[3];
     float lo1[3], hi1[3];
-    int32_t c0, c1;
+    int32_t c0, c1;  // >= 0: internal node index (mesh-relative); < 0: ~c = sorted triangle position
     int32_t pad0, pad1;
 };
 
@@ -118,7 +141,6 @@ struct DevMesh {
     int32_t gate_tri_offset;  // first of this mesh's 12 gate triangles in DevScene::gate_tri
     int32_t same_xform;       // the Box and the mesh share one transformation (always so in the reference's scenes)
     int32_t pad[2];
-    float qbase[3], qscale[3];  // node grid: coordinate = qbase + q * qscale
 };
 
 // What the plane test of find_closest reads, one 32-byte record per plane of the object list.
@@ -500,51 +522,57 @@ RT_HD void tri_test_flat(const f4 *tt, int32_t k, uint32_t key, v3 o, v3 d, TriB
     best.key = ok ? key : best.key;
 }
 
-constexpr int32_t kTraversalDone = 0x7fffffff;
-
-
-// Closest triangle of a mesh for a local-space ray: stack traversal of the mesh's LBVH in
-// "while-while" form -- every lane walks inner nodes until it holds a leaf (or is finished), then
-// the lanes holding leaves test their triangles together.  Near child first, far child pushed; a
-// child is skipped when its entry distance exceeds the best t so far (ties are kept so that the
-// tie-break on keys sees every candidate).
-// Stack is any type with reset() / push(int) / pop() / empty().
+// Closest triangle of a mesh for the local-space rays of a whole wave: PACKET traversal of the
+// mesh's LBVH.  The wave walks the tree once, with one wave-uniform node index and one stack; every
+// lane tests the node's two child boxes against its own ray, and a child is visited when ANY lane
+// reaches it (the lanes that do are recorded as a 64-bit mask with the stack entry).  Node and
+// triangle records are therefore fetched by scalar loads and there is no per-lane stack and no
+// divergent control flow.  A lane only tests triangles of leaves whose box its own ray entered
+// within its current best t, exactly the triangles a private traversal would test, so the result
+// is identical to the reference's linear scan.  Rays of one wave come from one 8x8 pixel block (or
+// its shadow / bounce rays) and share most of their path through the tree.
+// `want`: this lane's ray takes part.  Stack: put(slot, node, mask) / get(slot, node, mask).
 template <bool COUNT, class Stack>
-RT_HD void bvh_closest(const DevScene &S, const DevMesh &m, v3 o, v3 d, TriBest &best, Stack &stk, Work &wk) {
+RT_HD void bvh_closest_packet(const DevScene &S, const DevMesh &m, v3 o, v3 d, bool want, TriBest &best, Stack &stk, Work &wk) {
+    if (wave_ballot(want) == 0) return;
     const BvhNode *nodes = S.nodes + m.node_offset;
     const f4 *tt = S.tri_test + 3 * (size_t)m.tri_offset;
     const uint32_t *keys = S.tri_key + m.tri_offset;
     // A zero direction component would give inf - inf = NaN in the fused slab test; a huge finite
     // reciprocal keeps the sign logic (the ray then counts as parallel to that slab).
     v3 inv = V3(safe_rcp(d.x), safe_rcp(d.y), safe_rcp(d.z));
-    // grid coordinates are decoded inside the slab test: t = (qbase + q*qscale - o) * inv
-    //                                                      = q * (qscale*inv) - (o - qbase)*inv
-    v3 sinv = V3(m.qscale[0], m.qscale[1], m.qscale[2]) * inv;
-    v3 oi = (o - V3(m.qbase[0], m.qbase[1], m.qbase[2])) * inv;
-    stk.reset();
+    v3 oi = o * inv;
+    const uint64_t my_bit = 1ull << wave_lane();
+    int sp = 0;  // wave-uniform stack height
     int32_t cur = m.tri_count == 1 ? ~0 : 0;
-    while (cur != kTraversalDone) {
-        while (cur >= 0 && cur != kTraversalDone) {
-            const u4 *np = reinterpret_cast<const u4 *>(nodes + cur);
-            u4 a = np[0], b = np[1];
-            if (COUNT) wk.box += 2;
+    bool in = want;
+    for (;;) {
+        if (cur >= 0) {
+            const BvhNode &nd = nodes[cur];
+            if (COUNT && in) wk.box += 2;
             float n0, n1;
-            bool h0 = slab_fused((float)(a.x & 0xffffu), (float)(a.x >> 16), (float)(a.y & 0xffffu), (float)(a.y >> 16),
-                                 (float)(a.z & 0xffffu), (float)(a.z >> 16), sinv, oi, best.t, n0);
-            bool h1 = slab_fused((float)(a.w & 0xffffu), (float)(a.w >> 16), (float)(b.x & 0xffffu), (float)(b.x >> 16),
-                                 (float)(b.y & 0xffffu), (float)(b.y >> 16), sinv, oi, best.t, n1);
-            int32_t c0 = (int32_t)b.z, c1 = (int32_t)b.w;
-            bool second_first = h1 & (!h0 | (n1 < n0));
-            int32_t nearc = second_first ? c1 : c0, farc = second_first ? c0 : c1;
-            if (h0 & h1) stk.push(farc);
-            if (h0 | h1) cur = nearc;
-            else cur = stk.empty() ? kTraversalDone : stk.pop();
-        }
-        if (cur < 0) {
+            bool h0 = in & slab_fused(nd.lo0[0], nd.lo0[1], nd.lo0[2], nd.hi0[0], nd.hi0[1], nd.hi0[2], inv, oi, best.t, n0);
+            bool h1 = in & slab_fused(nd.lo1[0], nd.lo1[1], nd.lo1[2], nd.hi1[0], nd.hi1[1], nd.hi1[2], inv, oi, best.t, n1);
+            uint64_t b0 = wave_ballot(h0), b1 = wave_ballot(h1);
+            // when both children are needed: first the one that more lanes would enter first
+            uint64_t pref1 = wave_ballot(h1 & (!h0 | (n1 < n0)));
+            bool both = (b0 != 0) & (b1 != 0);
+            bool second_first = both ? 2 * popc64(pref1) > popc64(b0 | b1) : b0 == 0;
+            int32_t c0 = nd.c0, c1 = nd.c1;
+            if (both) stk.put(sp++, second_first ? c0 : c1, second_first ? b0 : b1);
+            if ((b0 | b1) != 0) {
+                cur = second_first ? c1 : c0;
+                in = second_first ? h1 : h0;
+                continue;
+            }
+        } else {
             int32_t k = ~cur;
-            tri_test_flat<COUNT>(tt, k, keys[k], o, d, best, wk);
-            cur = stk.empty() ? kTraversalDone : stk.pop();
+            if (in) tri_test_flat<COUNT>(tt, k, keys[k], o, d, best, wk);
         }
+        if (sp == 0) break;
+        uint64_t mask;
+        stk.get(--sp, cur, mask);
+        in = (mask & my_bit) != 0;
     }
 }
 
@@ -568,12 +596,13 @@ struct MeshHit {
 // first and the 12 exact triangle tests run only for rays that found a triangle (the gate is a
 // conjunct of the result, so the order does not matter).
 template <bool COUNT, class Stack>
-RT_HD bool mesh_geom(const DevScene &S, const DevMesh &m, v3 ro, v3 rd, v3 winv, v3 woi, int accel, float clip, MeshHit &mh, Stack &stk, Work &wk) {
-    if (m.tri_count <= 0) return false;
+RT_HD bool mesh_geom(const DevScene &S, const DevMesh &m, v3 ro, v3 rd, v3 winv, v3 woi, bool want, int accel, float clip, MeshHit &mh, Stack &stk, Work &wk) {
+    // phase 1, per lane: cheap rejections
     float tn;
-    if (COUNT) wk.box++;
-    if (!slab_fused(m.world_lo[0], m.world_lo[1], m.world_lo[2], m.world_hi[0], m.world_hi[1], m.world_hi[2], winv, woi, INFINITY, tn)) return false;
-    if (has_nan(ro) || has_nan(rd)) return false;  // every triangle test fails on NaN inputs
+    if (COUNT && want) wk.box++;
+    want = want & (m.tri_count > 0) &
+           slab_fused(m.world_lo[0], m.world_lo[1], m.world_lo[2], m.world_hi[0], m.world_hi[1], m.world_hi[2], winv, woi, INFINITY, tn);
+    want = want & !(has_nan(ro) | has_nan(rd));  // every triangle test fails on NaN inputs
     v3 d = xform_dir(m.to_local, rd);
     v3 o = xform_point(m.to_local, ro);
     v3 bo = o, bd = d;
@@ -583,28 +612,28 @@ RT_HD bool mesh_geom(const DevScene &S, const DevMesh &m, v3 ro, v3 rd, v3 winv,
             bo = xform_point(m.box_to_local, ro);
         }
         v3 binv = V3(safe_rcp(bd.x), safe_rcp(bd.y), safe_rcp(bd.z));
-        if (COUNT) wk.box++;
-        if (!slab_fused(m.gate_lo[0], m.gate_lo[1], m.gate_lo[2], m.gate_hi[0], m.gate_hi[1], m.gate_hi[2], binv, bo * binv, INFINITY, tn)) return false;
-        if (bo.x > m.gate_in_lo[0] && bo.x < m.gate_in_hi[0] && bo.y > m.gate_in_lo[1] && bo.y < m.gate_in_hi[1] &&
-            bo.z > m.gate_in_lo[2] && bo.z < m.gate_in_hi[2])
-            return false;
+        if (COUNT && want) wk.box++;
+        want = want & slab_fused(m.gate_lo[0], m.gate_lo[1], m.gate_lo[2], m.gate_hi[0], m.gate_hi[1], m.gate_hi[2], binv, bo * binv, INFINITY, tn);
+        bool inside = (bo.x > m.gate_in_lo[0]) & (bo.x < m.gate_in_hi[0]) & (bo.y > m.gate_in_lo[1]) & (bo.y < m.gate_in_hi[1]) &
+                      (bo.z > m.gate_in_lo[2]) & (bo.z < m.gate_in_hi[2]);
+        want = want & !inside;
     }
+    // phase 2, whole wave: the tree
     TriBest best;
     best.t = clip; best.k = -1; best.key = 0xffffffffu;
     if (accel == RT_ACCEL_BRUTE) {
-        const f4 *tt = S.tri_test + 3 * (size_t)m.tri_offset;
-        const uint32_t *keys = S.tri_key + m.tri_offset;
-        for (int32_t k = 0; k < m.tri_count; k++) tri_test<COUNT>(tt, k, keys[k], o, d, best, wk);
+        if (want) {
+            const f4 *tt = S.tri_test + 3 * (size_t)m.tri_offset;
+            const uint32_t *keys = S.tri_key + m.tri_offset;
+            for (int32_t k = 0; k < m.tri_count; k++) tri_test<COUNT>(tt, k, keys[k], o, d, best, wk);
+        }
     } else {
-        bvh_closest<COUNT>(S, m, o, d, best, stk, wk);
+        bvh_closest_packet<COUNT>(S, m, o, d, want, best, stk, wk);
     }
+    // phase 3, per lane: the exact Box gate and the acceptance inputs, for lanes that found a triangle
     if (best.k < 0) return false;
     if (m.boxed) {
         if (COUNT) wk.gate++;
-        if (!m.same_xform) {  // recomputed rather than kept live across the traversal
-            bd = xform_dir(m.box_to_local, rd);
-            bo = xform_point(m.box_to_local, ro);
-        }
         const f4 *gt = S.gate_tri + 3 * (size_t)m.gate_tri_offset;
         bool any = false;
         for (int i = 0; i < 12; i++) any = any || tri_hits(gt, i, bo, bd);
@@ -694,9 +723,10 @@ RT_HD void find_closest(const DevScene &S, v3 ro, v3 rd, int accel, float clip, 
     v3 woi = ro * winv;
     for (int32_t i = 0; i < S.n_meshes; i++) {
         int32_t idx = S.mesh_obj[i];
-        if (idx < 0 || best.distance < occl) continue;
+        if (idx < 0) continue;  // wave-uniform
         MeshHit mh;
-        if (mesh_geom<COUNT>(S, S.meshes[i], ro, rd, winv, woi, accel, clip, mh, stk, wk) && mh.from_outside && closer(mh.distance, idx, best)) {
+        bool want = !(best.distance < occl);
+        if (mesh_geom<COUNT>(S, S.meshes[i], ro, rd, winv, woi, want, accel, clip, mh, stk, wk) && mh.from_outside && closer(mh.distance, idx, best)) {
             best.distance = mh.distance; best.object = idx; best.t = mh.t; best.k = mh.k;
         }
     }
@@ -757,7 +787,7 @@ RT_HD void intersect_object(const DevScene &S, int32_t k, v3 ro, v3 rd, int acce
     } else if (ob.kind == RT_OBJ_MESH) {
         MeshHit mh;
         v3 winv = V3(safe_rcp(rd.x), safe_rcp(rd.y), safe_rcp(rd.z));
-        hit = mesh_geom<COUNT>(S, S.meshes[ob.index], ro, rd, winv, ro * winv, accel, INFINITY, mh, stk, wk);
+        hit = mesh_geom<COUNT>(S, S.meshes[ob.index], ro, rd, winv, ro * winv, true, accel, INFINITY, mh, stk, wk);
         if (hit) { c.t = mh.t; c.k = mh.k; c.distance = mh.distance; from_outside = mh.from_outside; }
     } else {
         QuadricHit q;

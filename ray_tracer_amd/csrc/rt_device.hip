@@ -30,18 +30,28 @@ constexpr int kNumCounters = 10;
 
 // ------------------------------------------------------------------ traversal stack in LDS
 
-// One column of a [kStackDepth][kBlock] int array per thread: entry e of thread t lives at
-// e * kBlock + t, so a wave's accesses fall on 64 consecutive words (no bank conflicts).
-struct LdsStack {
-    int32_t *base;
-    int sp;
-    __device__ __forceinline__ void reset() { sp = 0; }
-    __device__ __forceinline__ bool empty() const { return sp == 0; }
-    __device__ __forceinline__ void push(int32_t v) {
-        if (sp < kStackDepth) { base[sp * kBlock] = v; sp++; }  // depth is validated at build time
+// The packet traversal keeps ONE stack per wave: entries of (node, 64-bit lane mask), three LDS
+// words each.  All lanes write / read the same words (a broadcast access); the values are made
+// scalar again with readfirstlane.
+constexpr int kWavesPerBlock = kBlock / 64;
+constexpr int kStackWords = 3 * kStackDepth;
+struct WaveStack {
+    uint32_t *base;  // this wave's kStackWords words of LDS
+    __device__ __forceinline__ void put(int slot, int32_t node, uint64_t mask) {
+        if (slot < kStackDepth) {  // never false: the tree height is validated at build time
+            base[3 * slot] = (uint32_t)node; base[3 * slot + 1] = (uint32_t)mask; base[3 * slot + 2] = (uint32_t)(mask >> 32);
+        }
     }
-    __device__ __forceinline__ int32_t pop() { sp--; return base[sp * kBlock]; }
+    __device__ __forceinline__ void get(int slot, int32_t &node, uint64_t &mask) {
+        node = __builtin_amdgcn_readfirstlane((int32_t)base[3 * slot]);
+        uint32_t lo = __builtin_amdgcn_readfirstlane(base[3 * slot + 1]), hi = __builtin_amdgcn_readfirstlane(base[3 * slot + 2]);
+        mask = ((uint64_t)hi << 32) | lo;
+    }
 };
+#define RT_WAVE_STACK(name)                                              \
+    __shared__ uint32_t name##_lds[kWavesPerBlock * kStackWords];        \
+    WaveStack name;                                                      \
+    name.base = name##_lds + (threadIdx.x >> 6) * kStackWords
 
 __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -107,7 +117,7 @@ __global__ void k_children(const unsigned long long *keys, int n, int32_t *c0, i
 // so a workgroup barrier is enough to order a pass after the previous one.
 __global__ __launch_bounds__(1024) void k_fit(int n, const int32_t *c0s, const int32_t *c1s, const f4 *tt, float pad,
                                               int32_t *done_pass, float *node_lo, float *node_hi, int32_t *height,
-                                              const DevMesh *mesh, BvhNode *nodes, int32_t *root_height) {
+                                              BvhNode *nodes, int32_t *root_height) {
     __shared__ int s_left;
     int n_int = n - 1;
     for (int i = threadIdx.x; i < n_int; i += blockDim.x) done_pass[i] = 0;
@@ -117,7 +127,7 @@ __global__ __launch_bounds__(1024) void k_fit(int n, const int32_t *c0s, const i
         __syncthreads();
         int left = 0;
         for (int i = threadIdx.x; i < n_int; i += blockDim.x)
-            if (lbvh_fit_node(i, pass, c0s, c1s, tt, pad, done_pass, node_lo, node_hi, height, mesh->qbase, mesh->qscale, nodes) == 2) left++;
+            if (lbvh_fit_node(i, pass, c0s, c1s, tt, pad, done_pass, node_lo, node_hi, height, nodes) == 2) left++;
         if (left) atomicAdd(&s_left, left);
         __threadfence_block();
         __syncthreads();
@@ -141,10 +151,7 @@ struct RenderArgs {
 template <int F, bool COUNT>
 __global__ __launch_bounds__(kBlock, 4) void k_render(DevScene S, RenderArgs a, float *rgb_tiles, uint8_t *rgb8_tiles,
                                                    unsigned long long *counters) {
-    __shared__ int32_t lds_stack[kStackDepth * kBlock];
-    LdsStack stk;
-    stk.base = lds_stack + threadIdx.x;
-    stk.sp = 0;
+    RT_WAVE_STACK(stk);
     int tile = blockIdx.x * a.world_size + a.rank;
     int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     int px = (wave & 1) * 8 + (lane & 7), py = (wave >> 1) * 8 + (lane >> 3);
@@ -188,10 +195,7 @@ __global__ void k_untile(const T *shards, T *frame, int width, int height, int t
 __global__ __launch_bounds__(kBlock) void k_trace_rays(DevScene S, long long n, const float *o, const float *d,
                                                        int max_depth, int accel, rt_hit_record *hits, float *radiance,
                                                        unsigned long long *counters) {
-    __shared__ int32_t lds_stack[kStackDepth * kBlock];
-    LdsStack stk;
-    stk.base = lds_stack + threadIdx.x;
-    stk.sp = 0;
+    RT_WAVE_STACK(stk);
     long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     Work wk;
     work_zero(wk);
@@ -206,10 +210,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_rays(DevScene S, long long n, 
 
 __global__ __launch_bounds__(kBlock) void k_intersect_object(DevScene S, int object, long long n, const float *o,
                                                              const float *d, int accel, rt_hit_record *hits) {
-    __shared__ int32_t lds_stack[kStackDepth * kBlock];
-    LdsStack stk;
-    stk.base = lds_stack + threadIdx.x;
-    stk.sp = 0;
+    RT_WAVE_STACK(stk);
     long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n) return;
     Work wk;
@@ -491,7 +492,7 @@ extern "C" int rt_build_accel(rt_ctx *ctx) {
             hipLaunchKernelGGL(k_children, dim3((n + 255) / 256), blk, 0, ctx->stream, d_keys, n, d_c0, d_c1);
             hipLaunchKernelGGL(k_fit, dim3(1), dim3(1024), 0, ctx->stream, n, d_c0, d_c1,
                                ctx->d_tri_test + 3 * (size_t)m.tri_offset, ctx->mesh_build[i].pad, d_done, d_lo, d_hi, d_height,
-                               ctx->d_meshes + i, ctx->d_nodes + m.node_offset, d_root + i);
+                               ctx->d_nodes + m.node_offset, d_root + i);
         }
     }
     (void)hipEventRecord(ctx->ev1, ctx->stream);
@@ -737,11 +738,7 @@ extern "C" int rt_debug_copy_bvh(rt_ctx *ctx, int32_t mesh, float *nodes, int32_
     int nn = ctx->built ? std::max(m.tri_count - 1, 0) : 0;
     if (n_nodes) *n_nodes = nn;
     if (n_tris) *n_tris = m.tri_count;
-    if (nodes && nn) {
-        std::vector<BvhNode> q(nn);
-        RT_HIP(hipMemcpy(q.data(), ctx->d_nodes + m.node_offset, (size_t)nn * sizeof(BvhNode), hipMemcpyDeviceToHost));
-        for (int i = 0; i < nn; i++) dequantise_node(q[i], m.qbase, m.qscale, reinterpret_cast<BvhNodeF *>(nodes)[i]);
-    }
+    if (nodes && nn) RT_HIP(hipMemcpy(nodes, ctx->d_nodes + m.node_offset, (size_t)nn * sizeof(BvhNode), hipMemcpyDeviceToHost));
     if (order && m.tri_count) RT_HIP(hipMemcpy(order, ctx->d_tri_orig + m.tri_offset, (size_t)m.tri_count * sizeof(int32_t), hipMemcpyDeviceToHost));
     return RT_OK;
 }

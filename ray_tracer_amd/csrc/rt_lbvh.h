@@ -101,40 +101,14 @@ RT_HD void tri_bounds(const f4 *tt, int k, float pad, float *lo, float *hi) {
 // holds the number of the pass that completed it.  A node may be completed in pass `pass` once each
 // child is a leaf or was completed in an EARLIER pass (so its bounds are already in memory).
 // Returns 0: was already done, 1: completed now, 2: still waiting.
-// lower / upper bound of a coordinate on the node grid, one unit of slack on top of the rounding
-RT_HD uint16_t quant_lo(float x, float base, float inv_scale) {
-    float q = floorf((x - base) * inv_scale) - 1.0f;
-    return (uint16_t)(q == q ? fminf(fmaxf(q, 0.0f), 65535.0f) : 0.0f);
-}
-RT_HD uint16_t quant_hi(float x, float base, float inv_scale) {
-    float q = ceilf((x - base) * inv_scale) + 1.0f;
-    return (uint16_t)(q == q ? fminf(fmaxf(q, 0.0f), 65535.0f) : 65535.0f);
-}
-RT_HD void quantise_node(const BvhNodeF &f, const float *qbase, const float *qscale, BvhNode &out) {
-    for (int a = 0; a < 3; a++) {
-        float is = qscale[a] > 0 ? 1.0f / qscale[a] : 0.0f;
-        out.q[a] = quant_lo(f.lo0[a], qbase[a], is); out.q[3 + a] = quant_hi(f.hi0[a], qbase[a], is);
-        out.q[6 + a] = quant_lo(f.lo1[a], qbase[a], is); out.q[9 + a] = quant_hi(f.hi1[a], qbase[a], is);
-    }
-    out.c0 = f.c0; out.c1 = f.c1;
-}
-RT_HD void dequantise_node(const BvhNode &n, const float *qbase, const float *qscale, BvhNodeF &f) {
-    for (int a = 0; a < 3; a++) {
-        f.lo0[a] = qbase[a] + n.q[a] * qscale[a]; f.hi0[a] = qbase[a] + n.q[3 + a] * qscale[a];
-        f.lo1[a] = qbase[a] + n.q[6 + a] * qscale[a]; f.hi1[a] = qbase[a] + n.q[9 + a] * qscale[a];
-    }
-    f.c0 = n.c0; f.c1 = n.c1; f.pad0 = f.pad1 = 0;
-}
-
 RT_HD int lbvh_fit_node(int i, int pass, const int32_t *c0s, const int32_t *c1s, const f4 *tt, float pad,
-                        int32_t *done_pass, float *node_lo, float *node_hi, int32_t *height, const float *qbase,
-                        const float *qscale, BvhNode *nodes) {
+                        int32_t *done_pass, float *node_lo, float *node_hi, int32_t *height, BvhNode *nodes) {
     if (done_pass[i]) return 0;
     int32_t c0 = c0s[i], c1 = c1s[i];
     int d0 = c0 < 0 ? 0 : done_pass[c0], d1 = c1 < 0 ? 0 : done_pass[c1];
     bool r0 = c0 < 0 || (d0 != 0 && d0 < pass), r1 = c1 < 0 || (d1 != 0 && d1 < pass);
     if (!(r0 && r1)) return 2;
-    BvhNodeF nd;
+    BvhNode nd;
     int h0 = 0, h1 = 0;
     if (c0 < 0) tri_bounds(tt, ~c0, pad, nd.lo0, nd.hi0);
     else { for (int a = 0; a < 3; a++) { nd.lo0[a] = node_lo[3 * c0 + a]; nd.hi0[a] = node_hi[3 * c0 + a]; } h0 = height[c0]; }
@@ -146,7 +120,7 @@ RT_HD int lbvh_fit_node(int i, int pass, const int32_t *c0s, const int32_t *c1s,
         node_hi[3 * i + a] = fmaxf(nd.hi0[a], nd.hi1[a]);
     }
     height[i] = 1 + (h0 > h1 ? h0 : h1);
-    quantise_node(nd, qbase, qscale, nodes[i]);
+    nodes[i] = nd;
     done_pass[i] = pass;
     return 1;
 }

@@ -154,13 +154,6 @@ inline int prepare_meshes(const rt_scene_desc *sc, std::vector<DevMesh> &meshes,
             }
         }
         mb.pad = std::max(maxabs * 2e-5f, 1e-30f);
-        // node grid: 65535 cells across the padded bounds (plus a margin of two pads)
-        for (int a = 0; a < 3; a++) {
-            bool ok = std::isfinite(mb.lo[a]) && std::isfinite(mb.hi[a]) && mb.hi[a] >= mb.lo[a];
-            float lo = ok ? mb.lo[a] - 3 * mb.pad : 0.0f, hi = ok ? mb.hi[a] + 3 * mb.pad : 0.0f;
-            dm.qbase[a] = lo;
-            dm.qscale[a] = (hi - lo) / 65535.0f;
-        }
         float gmax = 0;
         for (int a = 0; a < 3; a++) gmax = std::max(gmax, std::max(std::fabs(m.box_min[a]), std::fabs(m.box_max[a])));
         float gpad = std::isfinite(gmax) ? std::max(gmax * 2e-5f, 1e-30f) : 0.0f;

@@ -18,14 +18,12 @@ using namespace rtc;
 
 namespace {
 
-struct VecStack {
-    int32_t data[kStackDepth];
-    int sp = 0;
+struct VecStack {  // the host build's "wave" is one lane
+    int32_t node[kStackDepth];
+    uint64_t mask[kStackDepth];
     int max_sp = 0;
-    void reset() { sp = 0; }
-    bool empty() const { return sp == 0; }
-    void push(int32_t v) { if (sp < kStackDepth) { data[sp++] = v; if (sp > max_sp) max_sp = sp; } }
-    int32_t pop() { return data[--sp]; }
+    void put(int slot, int32_t n, uint64_t m) { if (slot < kStackDepth) { node[slot] = n; mask[slot] = m; if (slot + 1 > max_sp) max_sp = slot + 1; } }
+    void get(int slot, int32_t &n, uint64_t &m) { n = node[slot]; m = mask[slot]; }
 };
 
 struct Twin {
@@ -146,7 +144,7 @@ int twin_build_accel(void *h) {
             int left = 0;
             for (int i = 0; i < n - 1; i++)
                 if (lbvh_fit_node(i, pass, c0.data(), c1.data(), tt, t->build[mi].pad, done.data(), lo.data(), hi.data(), height.data(),
-                                  m.qbase, m.qscale, &t->nodes[m.node_offset]) == 2)
+                                  &t->nodes[m.node_offset]) == 2)
                     left++;
             if (!left) break;
         }
@@ -211,7 +209,7 @@ int twin_copy_bvh(void *h, int mesh, float *nodes, int32_t *order) {
     Twin *t = static_cast<Twin *>(h);
     const DevMesh &m = t->meshes[mesh];
     int nn = std::max(m.tri_count - 1, 0);
-    for (int i = 0; nodes && i < nn; i++) dequantise_node(t->nodes[m.node_offset + i], m.qbase, m.qscale, reinterpret_cast<BvhNodeF *>(nodes)[i]);
+    if (nodes && nn) std::memcpy(nodes, &t->nodes[m.node_offset], (size_t)nn * sizeof(BvhNode));
     if (order) std::memcpy(order, &t->tri_orig[m.tri_offset], (size_t)m.tri_count * sizeof(int32_t));
     return nn;
 }

@@ -95,8 +95,8 @@ def test_lbvh_structure(twin, host_scene):
             sys.setrecursionlimit(10000)
             _, _, height = bounds(0)
             assert np.all(seen_leaf == 1) and np.all(seen_node == 1)
-            assert height <= 32
-        assert tw.height <= 32
+            assert height <= 48
+        assert tw.height <= 48
 
 
 def test_degenerate_meshes(oracle_scene):
