@@ -28,10 +28,11 @@ def timeit(name, scene, w=3840, h=2160, grid=4):
     print(f"{name:32s} kernel {c.last_trace_ms:7.3f} ms  rays {c.rays/1e6:7.1f} M  {c.rays/c.last_trace_ms/1e3:8.0f} Mrays/s")
     ctx.close()
 
-timeit("room+teapot, 2 lights", room())
-timeit("room only, 2 lights", room(mesh=False))
-timeit("room+teapot, 1 light", room(lights=1))
-timeit("room only, 1 light", room(mesh=False, lights=1))
-timeit("room+teapot, 0 lights", room(lights=0))
-timeit("room only, 0 lights", room(mesh=False, lights=0))
-timeit("floor+teapot, 2 lights", room(planes=1))
+if __name__ == "__main__":
+    timeit("room+teapot, 2 lights", room())
+    timeit("room only, 2 lights", room(mesh=False))
+    timeit("room+teapot, 1 light", room(lights=1))
+    timeit("room only, 1 light", room(mesh=False, lights=1))
+    timeit("room+teapot, 0 lights", room(lights=0))
+    timeit("room only, 0 lights", room(mesh=False, lights=0))
+    timeit("floor+teapot, 2 lights", room(planes=1))

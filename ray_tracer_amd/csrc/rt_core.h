@@ -14,6 +14,7 @@
 
 #include <math.h>
 #include <stdint.h>
+#include <string.h>
 
 #include "rt_amd.h"
 
@@ -101,6 +102,42 @@ RT_HD int popc64(uint64_t x) {
     return __builtin_popcountll(x);
 #endif
 }
+// A value fetched through a wave-uniform address: keeps it in scalar registers and makes the
+// compiler complete the fetch HERE, so that several fetches issued just before share one wait
+// instead of each being delayed to (and waited for at) its first use.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+#else
+struct u32x16 {
+    uint32_t e[16];
+    uint32_t &operator[](int k) { return e[k]; }
+    const uint32_t &operator[](int k) const { return e[k]; }
+};
+#endif
+RT_HD void pin_scalar(u32x16 &v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("" : "+s"(v));
+#else
+    (void)v;
+#endif
+}
+// 64 bytes of a scene table through a wave-uniform address.  The tables are never written while a
+// trace kernel runs, so the read goes through the constant address space: always one scalar load.
+RT_HD u32x16 load_u32x16(const void *p) {  // p: 64-byte aligned on the device
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef const u32x16 __attribute__((address_space(4))) *const_ptr;
+    return *(const_ptr)(uintptr_t)p;
+#else
+    u32x16 v; memcpy(&v, p, sizeof v); return v;
+#endif
+}
+RT_HD float u2f(uint32_t u) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __uint_as_float(u);
+#else
+    float f; memcpy(&f, &u, 4); return f;
+#endif
+}
 RT_HD bool has_nan(v3 a) { return !(a.x == a.x) || !(a.y == a.y) || !(a.z == a.z); }
 
 // mat4 * vec4 of glm/detail/type_mat4x4.inl:561-572 on a matrix stored as four 3-row columns:
@@ -132,23 +169,49 @@ struct BvhNode {
     int32_t pad0, pad1;
 };
 
-struct DevMesh {
+// One mesh.  The first 64 bytes (MeshHead) are all that a ray needs to reject the mesh and to set up
+// the traversal; they are fetched as one scalar load, ahead of time.  The second block (to_local and
+// the gate boxes) is read only by waves with a ray inside the world box.
+struct MeshHead {
     float world_lo[3], world_hi[3];  // padded world-space bounds of the (gate box of the) mesh: first, cheapest rejection
-    float to_local[12], to_world[12], normal_mat[12], box_to_local[12];
+    int32_t object;                  // index in the object list, -1: not in the list
+    int32_t tri_count, boxed;
+    int32_t same_xform;              // the Box and the mesh share one transformation (always so in the reference's scenes)
+    int32_t tri_offset, node_offset;
+    int32_t gate_tri_offset;         // first of this mesh's 12 gate triangles in DevScene::gate_tri
+    int32_t pad[3];
+};
+struct alignas(64) DevMesh : MeshHead {
+    float to_local[12];
     float gate_lo[3], gate_hi[3];        // padded Box bounds for the conservative pre-test
     float gate_in_lo[3], gate_in_hi[3];  // shrunken Box bounds: an origin inside sees only back faces
-    int32_t tri_offset, tri_count, boxed, node_offset;
-    int32_t gate_tri_offset;  // first of this mesh's 12 gate triangles in DevScene::gate_tri
-    int32_t same_xform;       // the Box and the mesh share one transformation (always so in the reference's scenes)
-    int32_t pad[2];
+    float box_to_local[12], to_world[12], normal_mat[12];
+    int32_t pad2[4];
 };
+static_assert(sizeof(MeshHead) == 64 && sizeof(DevMesh) == 320, "DevMesh layout");
 
-// What the plane test of find_closest reads, one 32-byte record per plane of the object list.
+// What the plane tests of find_closest read.  Planes whose normal is exactly +-e_a (the walls of a
+// room) take 16 bytes, so that four of them arrive with one 64-byte scalar load; the others take 32
+// bytes and arrive two at a time.  Both arrays are padded with inert records (axis / object 0 / -1)
+// to a multiple of the group size.
+// cannot_shadow: a shadow ray runs from a surface point to light l and only asks whether something
+// lies closer than the light.  A plane is hit on its front face only, i.e. by a ray that passes from
+// its front side to its back side; when the light is on the front side (by a margin far above
+// rounding) the crossing lies beyond the light, so the plane cannot change the answer and the test is
+// skipped for that light's shadow rays.  In a room lit from inside this removes every wall from
+// every shadow ray.
+struct AxisPlaneRec {
+    int32_t axis;    // +-(a+1): the normal is +-e_a; 0: padding
+    float coord;     // point[a]
+    int32_t object;  // index in the object list
+    uint32_t cannot_shadow;  // bit l: the plane can never lie between a surface point and light l (l < 32)
+};
 struct PlaneRec {
     float n[3], p[3];
-    int32_t object;  // index in the object list
-    int32_t plane;   // index in the plane array
+    int32_t object;  // index in the object list, -1: padding
+    uint32_t cannot_shadow;
 };
+constexpr int kAxisPlaneGroup = 4, kPlaneGroup = 2;
 
 struct DevTexture {
     int32_t kind;
@@ -161,9 +224,10 @@ struct DevScene {
     int32_t n_objects, n_lights;
     int32_t n_planes, n_spheres, n_cones, n_meshes;
     const rt_object *objects;
-    const int32_t *plane_obj, *sphere_obj, *cone_obj, *mesh_obj;  // index of each plane / ... in `objects`
-    int32_t n_plane_recs, pad0;
-    const PlaneRec *plane_recs;
+    const int32_t *plane_obj, *sphere_obj, *cone_obj;  // index of each plane / ... in `objects` (meshes: MeshHead::object)
+    int32_t n_axis_planes, n_gen_planes;  // padded counts
+    const AxisPlaneRec *axis_planes;
+    const PlaneRec *gen_planes;
     const rt_sphere *spheres;
     const rt_plane *planes;
     const rt_cone *cones;
@@ -516,7 +580,8 @@ RT_HD void tri_test_flat(const f4 *tt, int32_t k, uint32_t key, v3 o, v3 d, TriB
     v3 sn1 = cross(p2 - p, p3 - p);
     v3 sn2 = cross(p3 - p, p1 - p);
     v3 sn3 = cross(p1 - p, p2 - p);
-    ok = ok & !((dot(sn1, sn) < 0) | (dot(sn2, sn) < 0) | (dot(sn3, sn) < 0));
+    float e1 = dot(sn1, sn), e2 = dot(sn2, sn), e3 = dot(sn3, sn);
+    ok = ok & !((e1 < 0) | (e2 < 0) | (e3 < 0));
     best.t = ok ? t : best.t;
     best.k = ok ? k : best.k;
     best.key = ok ? key : best.key;
@@ -533,7 +598,7 @@ RT_HD void tri_test_flat(const f4 *tt, int32_t k, uint32_t key, v3 o, v3 d, TriB
 // its shadow / bounce rays) and share most of their path through the tree.
 // `want`: this lane's ray takes part.  Stack: put(slot, node, mask) / get(slot, node, mask).
 template <bool COUNT, class Stack>
-RT_HD void bvh_closest_packet(const DevScene &S, const DevMesh &m, v3 o, v3 d, bool want, TriBest &best, Stack &stk, Work &wk) {
+RT_HD void bvh_closest_packet(const DevScene &S, const MeshHead &m, v3 o, v3 d, bool want, TriBest &best, Stack &stk, Work &wk) {
     if (wave_ballot(want) == 0) return;
     const BvhNode *nodes = S.nodes + m.node_offset;
     const f4 *tt = S.tri_test + 3 * (size_t)m.tri_offset;
@@ -596,51 +661,53 @@ struct MeshHit {
 // first and the 12 exact triangle tests run only for rays that found a triangle (the gate is a
 // conjunct of the result, so the order does not matter).
 template <bool COUNT, class Stack>
-RT_HD bool mesh_geom(const DevScene &S, const DevMesh &m, v3 ro, v3 rd, v3 winv, v3 woi, bool want, int accel, float clip, MeshHit &mh, Stack &stk, Work &wk) {
+RT_HD bool mesh_geom(const DevScene &S, const MeshHead &h, const DevMesh &m, v3 ro, v3 rd, v3 winv, v3 woi, bool want, int accel, float clip, MeshHit &mh, Stack &stk, Work &wk) {
     // phase 1, per lane: cheap rejections
     float tn;
     if (COUNT && want) wk.box++;
-    want = want & (m.tri_count > 0) &
-           slab_fused(m.world_lo[0], m.world_lo[1], m.world_lo[2], m.world_hi[0], m.world_hi[1], m.world_hi[2], winv, woi, INFINITY, tn);
-    want = want & !(has_nan(ro) | has_nan(rd));  // every triangle test fails on NaN inputs
+    want = want & (h.tri_count > 0) &
+           slab_fused(h.world_lo[0], h.world_lo[1], h.world_lo[2], h.world_hi[0], h.world_hi[1], h.world_hi[2], winv, woi, INFINITY, tn);
+    if (wave_ballot(want) == 0) return false;  // the whole wave misses the mesh's world box
     v3 d = xform_dir(m.to_local, rd);
     v3 o = xform_point(m.to_local, ro);
     v3 bo = o, bd = d;
-    if (m.boxed) {
-        if (!m.same_xform) {
-            bd = xform_dir(m.box_to_local, rd);
-            bo = xform_point(m.box_to_local, ro);
-        }
+    if (!h.same_xform) {
+        bd = xform_dir(m.box_to_local, rd);
+        bo = xform_point(m.box_to_local, ro);
+    }
+    {   // evaluated for every mesh (no branch, so that to_local and the boxes arrive in one batch of loads);
+        // the outcome only counts for boxed meshes
+        bool boxed = h.boxed != 0;
         v3 binv = V3(safe_rcp(bd.x), safe_rcp(bd.y), safe_rcp(bd.z));
-        if (COUNT && want) wk.box++;
-        want = want & slab_fused(m.gate_lo[0], m.gate_lo[1], m.gate_lo[2], m.gate_hi[0], m.gate_hi[1], m.gate_hi[2], binv, bo * binv, INFINITY, tn);
+        if (COUNT && want && boxed) wk.box++;
+        bool g = slab_fused(m.gate_lo[0], m.gate_lo[1], m.gate_lo[2], m.gate_hi[0], m.gate_hi[1], m.gate_hi[2], binv, bo * binv, INFINITY, tn);
         bool inside = (bo.x > m.gate_in_lo[0]) & (bo.x < m.gate_in_hi[0]) & (bo.y > m.gate_in_lo[1]) & (bo.y < m.gate_in_hi[1]) &
                       (bo.z > m.gate_in_lo[2]) & (bo.z < m.gate_in_hi[2]);
-        want = want & !inside;
+        want = want & (!boxed | (g & !inside));
     }
     // phase 2, whole wave: the tree
     TriBest best;
     best.t = clip; best.k = -1; best.key = 0xffffffffu;
     if (accel == RT_ACCEL_BRUTE) {
         if (want) {
-            const f4 *tt = S.tri_test + 3 * (size_t)m.tri_offset;
-            const uint32_t *keys = S.tri_key + m.tri_offset;
-            for (int32_t k = 0; k < m.tri_count; k++) tri_test<COUNT>(tt, k, keys[k], o, d, best, wk);
+            const f4 *tt = S.tri_test + 3 * (size_t)h.tri_offset;
+            const uint32_t *keys = S.tri_key + h.tri_offset;
+            for (int32_t k = 0; k < h.tri_count; k++) tri_test<COUNT>(tt, k, keys[k], o, d, best, wk);
         }
     } else {
-        bvh_closest_packet<COUNT>(S, m, o, d, want, best, stk, wk);
+        bvh_closest_packet<COUNT>(S, h, o, d, want, best, stk, wk);
     }
     // phase 3, per lane: the exact Box gate and the acceptance inputs, for lanes that found a triangle
     if (best.k < 0) return false;
-    if (m.boxed) {
+    if (h.boxed) {
         if (COUNT) wk.gate++;
-        const f4 *gt = S.gate_tri + 3 * (size_t)m.gate_tri_offset;
+        const f4 *gt = S.gate_tri + 3 * (size_t)h.gate_tri_offset;
         bool any = false;
         for (int i = 0; i < 12; i++) any = any || tri_hits(gt, i, bo, bd);
         if (!any) return false;
     }
     mh.t = best.t;
-    mh.k = best.k + m.tri_offset;
+    mh.k = best.k + h.tri_offset;
     v3 p, n; v2 uv; int32_t orig;
     tri_surface(S, mh.k, mh.t, o, d, p, n, uv, mh.from_outside, orig);
     mh.distance = distance(ro, xform_point(m.to_world, p));
@@ -659,6 +726,29 @@ RT_HD void mesh_surface(const DevScene &S, const DevMesh &m, v3 ro, v3 rd, float
 }
 
 // ---------------------------------------------------------------- closest hit
+
+// Shading-only arithmetic.  Decisions (which object is hit, shadowed or not) and every value that
+// feeds a later ray use the reference's exact operations above; the colour arithmetic below may
+// use the hardware's 1-ulp reciprocal and exp2/log2 on the GPU, which stays orders of magnitude
+// inside the 1e-4 relative radiance bar.
+RT_HD float shade_rcp(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rcpf(x);
+#else
+    return 1.0f / x;
+#endif
+}
+// pow(x, y) for x in [0, 1], y >= 0 (Phong lobe, main.cpp:678)
+RT_HD float shade_pow(float x, float y) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (y <= 256.0f) {
+        if (y == 0.0f) return 1.0f;
+        return __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x));
+    }
+#endif
+    return powf(x, y);
+}
+
 
 // The winner of find_closest_hit, reduced to what is needed to rebuild the full hit record:
 // t is the ray parameter in the object's own space; k is the sorted triangle position (mesh) or
@@ -679,24 +769,73 @@ struct Closest {
 RT_HD bool closer(float dist, int32_t idx, const Closest &best) {
     return (dist > kMinDist) & ((dist < best.distance) | ((dist == best.distance) & (idx < best.object)));
 }
+// the common tail of both plane tests: estimate, wave-wide skip, exact quotient, acceptance
+template <bool COUNT>
+RT_HD void plane_accept(float DdotN, float PdotN, bool facing, int32_t idx, Closest &best, Work &wk) {
+    if (COUNT) wk.plane++;
+    float est = PdotN * shade_rcp(DdotN);
+    bool maybe = facing & (est > 0.5f * kMinDist) & !(est > best.distance * 1.00001f);
+    if (wave_ballot(maybe) != 0) {
+        float t = PdotN / DdotN;
+        bool ok = facing & (t > 0) & closer(t, idx, best);
+        best.distance = ok ? t : best.distance; best.object = ok ? idx : best.object; best.t = ok ? t : best.t;
+    }
+}
+template <bool COUNT>
+RT_HD void plane_axis_test(int32_t axis, float coord, int32_t idx, uint32_t skip, v3 ro, v3 rd, bool finite, Closest &best, Work &wk) {
+    if (axis == 0 || skip != 0) return;  // padding, or a plane that cannot shadow this wave's light (wave-uniform)
+    // (-q) / (-dd) == q / dd bit for bit, so the sign of the normal only decides `facing`
+    int a = (axis < 0 ? -axis : axis) - 1;
+    float dd = a == 0 ? rd.x : a == 1 ? rd.y : rd.z;
+    float oo = a == 0 ? ro.x : a == 1 ? ro.y : ro.z;
+    bool facing = finite & (axis < 0 ? dd > 0 : dd < 0);
+    plane_accept<COUNT>(dd, coord - oo, facing, idx, best, wk);
+}
+template <bool COUNT>
+RT_HD void plane_gen_test(const u32x16 &g, int at, uint32_t light_bit, v3 ro, v3 rd, Closest &best, Work &wk) {
+    int32_t idx = (int32_t)g[at + 6];
+    if (idx < 0 || (g[at + 7] & light_bit) != 0) return;  // padding, or cannot shadow this wave's light (wave-uniform)
+    v3 n = V3(u2f(g[at]), u2f(g[at + 1]), u2f(g[at + 2]));
+    float DdotN = dot(rd, n);
+    float PdotN = dot(V3(u2f(g[at + 3]), u2f(g[at + 4]), u2f(g[at + 5])) - ro, n);
+    plane_accept<COUNT>(DdotN, PdotN, DdotN < 0, idx, best, wk);
+}
+
 template <int F, bool COUNT, class Stack>
-RT_HD void find_closest(const DevScene &S, v3 ro, v3 rd, int accel, float clip, float occl, Closest &best, Stack &stk, Work &wk) {
+RT_HD void find_closest(const DevScene &S, v3 ro, v3 rd, int accel, int light, float clip, float occl, Closest &best, Stack &stk, Work &wk) {
+    // light: >= 0 when the ray is a shadow ray towards that light.  When all lanes of the wave are
+    // shadow rays towards the same light, planes that cannot shadow it are skipped.
+    int32_t light_u = wave_uniform(light);
+    uint32_t light_bit = (wave_ballot(light != light_u) == 0 && light_u >= 0 && light_u < 32) ? 1u << light_u : 0u;
     best.distance = INFINITY;
     best.object = -1;
     best.t = 0;
     best.k = 0;
-    // planes (Plane::intersect, main.cpp:222-237); the quotient is formed unconditionally so that
-    // there is no divergent exit
-    for (int32_t i = 0; i < S.n_plane_recs; i++) {
-        const PlaneRec &rec = S.plane_recs[i];
-        if (COUNT) wk.plane++;
-        v3 n = ld3(rec.n);
-        float DdotN = dot(rd, n);
-        float PdotN = dot(ld3(rec.p) - ro, n);
-        float t = PdotN / DdotN;
-        int32_t idx = rec.object;
-        bool ok = (DdotN < 0) & (t > 0) & closer(t, idx, best);
-        best.distance = ok ? t : best.distance; best.object = ok ? idx : best.object; best.t = ok ? t : best.t; best.k = ok ? 0 : best.k;
+    // planes (Plane::intersect, main.cpp:222-237).  A plane is skipped by the whole wave when no
+    // lane's ray faces it, or when a 1-ulp estimate of the quotient shows that no lane's hit could
+    // replace its current best; otherwise the exact quotient is formed by every lane (no divergence).
+    // For a normal that is exactly +-e_a the reference's dot products reduce exactly to the a-th
+    // components (x * 0 = +-0 and v + +-0 = v) as long as every component is finite; with a
+    // non-finite component they are NaN and the plane is missed, which `finite` reproduces.
+    // The order of the tests is free: closer() picks the same winner in any order.
+    float adx = fabsf(rd.x), ady = fabsf(rd.y), adz = fabsf(rd.z), aox = fabsf(ro.x), aoy = fabsf(ro.y), aoz = fabsf(ro.z);
+    bool finite = (adx < INFINITY) & (ady < INFINITY) & (adz < INFINITY) & (aox < INFINITY) & (aoy < INFINITY) & (aoz < INFINITY);
+    const bool meshes = (F & F_MESH) && S.n_meshes > 0;
+    u32x16 head_next = {};
+    if (meshes) head_next = load_u32x16(S.meshes);  // the first mesh head travels with the first planes
+    for (int32_t i = 0; i < S.n_axis_planes; i += kAxisPlaneGroup) {
+        u32x16 g = load_u32x16(S.axis_planes + i);
+        pin_scalar(g);
+        plane_axis_test<COUNT>((int32_t)g[0], u2f(g[1]), (int32_t)g[2], g[3] & light_bit, ro, rd, finite, best, wk);
+        plane_axis_test<COUNT>((int32_t)g[4], u2f(g[5]), (int32_t)g[6], g[7] & light_bit, ro, rd, finite, best, wk);
+        plane_axis_test<COUNT>((int32_t)g[8], u2f(g[9]), (int32_t)g[10], g[11] & light_bit, ro, rd, finite, best, wk);
+        plane_axis_test<COUNT>((int32_t)g[12], u2f(g[13]), (int32_t)g[14], g[15] & light_bit, ro, rd, finite, best, wk);
+    }
+    for (int32_t i = 0; i < S.n_gen_planes; i += kPlaneGroup) {
+        u32x16 g = load_u32x16(S.gen_planes + i);
+        pin_scalar(g);
+        plane_gen_test<COUNT>(g, 0, light_bit, ro, rd, best, wk);
+        plane_gen_test<COUNT>(g, 8, light_bit, ro, rd, best, wk);
     }
     if (F & F_QUADRIC)
     for (int32_t i = 0; i < S.n_spheres; i++) {
@@ -718,15 +857,21 @@ RT_HD void find_closest(const DevScene &S, v3 ro, v3 rd, int accel, float clip, 
             best.distance = q.distance; best.object = idx; best.t = q.t; best.k = q.cap ? 1 : 0;
         }
     }
-    if ((F & F_MESH) && S.n_meshes > 0) {
+    if (meshes) {
     v3 winv = V3(safe_rcp(rd.x), safe_rcp(rd.y), safe_rcp(rd.z));
     v3 woi = ro * winv;
-    for (int32_t i = 0; i < S.n_meshes; i++) {
-        int32_t idx = S.mesh_obj[i];
+    bool nan_o = has_nan(ro), nan_d = has_nan(rd);
+    bool valid = !(nan_o | nan_d);  // every triangle test fails on NaN inputs
+    const int32_t n_meshes = S.n_meshes;
+    for (int32_t i = 0; i < n_meshes; i++) {
+        union { u32x16 raw; MeshHead h; } head;
+        head.raw = head_next;
+        if (i + 1 < n_meshes) head_next = load_u32x16(S.meshes + i + 1);
+        int32_t idx = head.h.object;
         if (idx < 0) continue;  // wave-uniform
         MeshHit mh;
-        bool want = !(best.distance < occl);
-        if (mesh_geom<COUNT>(S, S.meshes[i], ro, rd, winv, woi, want, accel, clip, mh, stk, wk) && mh.from_outside && closer(mh.distance, idx, best)) {
+        bool want = valid & !(best.distance < occl);
+        if (mesh_geom<COUNT>(S, head.h, S.meshes[i], ro, rd, winv, woi, want, accel, clip, mh, stk, wk) && mh.from_outside && closer(mh.distance, idx, best)) {
             best.distance = mh.distance; best.object = idx; best.t = mh.t; best.k = mh.k;
         }
     }
@@ -787,7 +932,7 @@ RT_HD void intersect_object(const DevScene &S, int32_t k, v3 ro, v3 rd, int acce
     } else if (ob.kind == RT_OBJ_MESH) {
         MeshHit mh;
         v3 winv = V3(safe_rcp(rd.x), safe_rcp(rd.y), safe_rcp(rd.z));
-        hit = mesh_geom<COUNT>(S, S.meshes[ob.index], ro, rd, winv, ro * winv, true, accel, INFINITY, mh, stk, wk);
+        hit = mesh_geom<COUNT>(S, S.meshes[ob.index], S.meshes[ob.index], ro, rd, winv, ro * winv, true, accel, INFINITY, mh, stk, wk);
         if (hit) { c.t = mh.t; c.k = mh.k; c.distance = mh.distance; from_outside = mh.from_outside; }
     } else {
         QuadricHit q;
@@ -817,31 +962,10 @@ RT_HD v3 refract_dir(v3 i, v3 n, float index) {
     return a * alpha + b * beta;
 }
 
-// Shading-only arithmetic.  Decisions (which object is hit, shadowed or not) and every value that
-// feeds a later ray use the reference's exact operations above; the colour arithmetic below may
-// use the hardware's 1-ulp reciprocal and exp2/log2 on the GPU, which stays orders of magnitude
-// inside the 1e-4 relative radiance bar.
-RT_HD float shade_rcp(float x) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __builtin_amdgcn_rcpf(x);
-#else
-    return 1.0f / x;
-#endif
-}
-// pow(x, y) for x in [0, 1], y >= 0 (Phong lobe, main.cpp:678)
-RT_HD float shade_pow(float x, float y) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    if (y <= 256.0f) {
-        if (y == 0.0f) return 1.0f;
-        return __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x));
-    }
-#endif
-    return powf(x, y);
-}
-
 // What PhongModel (main.cpp:642-695) needs while the shadow rays of one hit are in flight.
 struct ShadeCtx {
     v3 point, normal, d_in;  // d_in: direction of the ray that produced the hit
+    v3 view;                 // normalize(-d_in)
     v3 color;                // running sum, starts at ambient_light * material.ambient
     v3 dc;                   // diffuse colour (texture(uv) or material.diffuse), x5 for image textures
     v2 uv;
@@ -854,6 +978,7 @@ template <int F, bool COUNT>
 RT_HD void shade_begin(const DevScene &S, const Surf &s, v3 d_in, ShadeCtx &sc, Work &wk) {
     const rt_material &m = S.materials[s.material];
     sc.point = s.point; sc.normal = s.normal; sc.d_in = d_in; sc.uv = s.uv;
+    sc.view = normalize(-d_in);
     sc.material = s.material; sc.from_outside = s.from_outside;
     sc.color = ld3(S.ambient) * ld3(m.ambient);
     const DevTexture *tex = ((F & F_TEXTURE) && m.texture >= 0) ? &S.textures[m.texture] : nullptr;
@@ -874,7 +999,7 @@ template <bool COUNT>
 RT_HD void shade_light(const DevScene &S, ShadeCtx &sc, int l, v3 L, float r, Work &wk) {
     if (COUNT) wk.shade++;
     const rt_material &m = S.materials[sc.material];
-    v3 view = normalize(-sc.d_in);
+    v3 view = sc.view;
     v3 R = reflect(-L, sc.normal);
     float NdotL = clamp01(dot(sc.normal, L));
     float VdotR = clamp01(dot(view, R));
@@ -926,7 +1051,7 @@ RT_HD void trace_loop(const DevScene &S, int max_depth, int accel, Stack &stk, W
     ShadeCtx sc;
     for (;;) {
         Closest c;
-        find_closest<F, COUNT>(S, o, d, accel, clip, occl, c, stk, wk);
+        find_closest<F, COUNT>(S, o, d, accel, light, clip, occl, c, stk, wk);
         bool shade_done = false, ray_done = false;
         if (light < 0) {
             if (primary) wk.rays_primary++; else wk.rays_secondary++;

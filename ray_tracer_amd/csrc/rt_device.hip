@@ -33,6 +33,9 @@ constexpr int kNumCounters = 10;
 // The packet traversal keeps ONE stack per wave: entries of (node, 64-bit lane mask), three LDS
 // words each.  All lanes write / read the same words (a broadcast access); the values are made
 // scalar again with readfirstlane.
+#ifndef RT_WAVES
+#define RT_WAVES 4  // resident waves per SIMD the render kernel is compiled for (register budget 512 / RT_WAVES)
+#endif
 constexpr int kWavesPerBlock = kBlock / 64;
 constexpr int kStackWords = 3 * kStackDepth;
 struct WaveStack {
@@ -149,7 +152,7 @@ struct RenderArgs {
 // Block b renders local tile b = global tile b * world_size + rank.  Each wave owns an 8x8 pixel
 // quadrant of the 16x16 tile so that its 64 rays are spatially coherent.
 template <int F, bool COUNT>
-__global__ __launch_bounds__(kBlock, 4) void k_render(DevScene S, RenderArgs a, float *rgb_tiles, uint8_t *rgb8_tiles,
+__global__ __launch_bounds__(kBlock, RT_WAVES) void k_render(DevScene S, RenderArgs a, float *rgb_tiles, uint8_t *rgb8_tiles,
                                                    unsigned long long *counters) {
     RT_WAVE_STACK(stk);
     int tile = blockIdx.x * a.world_size + a.rank;
@@ -390,21 +393,24 @@ extern "C" int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *sc) {
     if ((rc = dev_alloc(ctx, &d_tex, tex.size(), tex.data()))) return rc;
     std::vector<int32_t> plane_obj, sphere_obj, cone_obj, mesh_obj;
     kind_to_object(sc, plane_obj, sphere_obj, cone_obj, mesh_obj);
-    int32_t *d_plane_obj, *d_sphere_obj, *d_cone_obj, *d_mesh_obj;
+    int32_t *d_plane_obj, *d_sphere_obj, *d_cone_obj;
     if ((rc = dev_alloc(ctx, &d_plane_obj, plane_obj.size(), plane_obj.data()))) return rc;
     if ((rc = dev_alloc(ctx, &d_sphere_obj, sphere_obj.size(), sphere_obj.data()))) return rc;
     if ((rc = dev_alloc(ctx, &d_cone_obj, cone_obj.size(), cone_obj.data()))) return rc;
-    if ((rc = dev_alloc(ctx, &d_mesh_obj, mesh_obj.size(), mesh_obj.data()))) return rc;
-    std::vector<PlaneRec> plane_recs;
-    make_plane_recs(sc, plane_obj, plane_recs);
-    PlaneRec *d_plane_recs;
-    if ((rc = dev_alloc(ctx, &d_plane_recs, plane_recs.size(), plane_recs.data()))) return rc;
+    std::vector<AxisPlaneRec> axis_planes;
+    std::vector<PlaneRec> gen_planes;
+    make_plane_recs(sc, plane_obj, axis_planes, gen_planes);
+    AxisPlaneRec *d_axis_planes;
+    PlaneRec *d_gen_planes;
+    if ((rc = dev_alloc(ctx, &d_axis_planes, axis_planes.size(), axis_planes.data()))) return rc;
+    if ((rc = dev_alloc(ctx, &d_gen_planes, gen_planes.size(), gen_planes.data()))) return rc;
 
     // meshes: bounds, padding, gate triangles, node ranges
     ctx->n_meshes = sc->n_meshes;
     ctx->n_triangles = sc->n_triangles;
     std::vector<f4> gate;
     int node_total = prepare_meshes(sc, ctx->meshes, ctx->mesh_build, gate);
+    for (int i = 0; i < sc->n_meshes; i++) ctx->meshes[i].object = mesh_obj[i];
     ctx->n_nodes = node_total;
     f4 *d_gate;
     if ((rc = dev_alloc(ctx, &d_gate, gate.size(), gate.data()))) return rc;
@@ -424,8 +430,9 @@ extern "C" int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *sc) {
     DevScene &S = ctx->S;
     S.n_objects = sc->n_objects; S.n_lights = sc->n_lights;
     S.n_planes = sc->n_planes; S.n_spheres = sc->n_spheres; S.n_cones = sc->n_cones; S.n_meshes = sc->n_meshes;
-    S.n_plane_recs = (int32_t)plane_recs.size(); S.pad0 = 0; S.plane_recs = d_plane_recs;
-    S.plane_obj = d_plane_obj; S.sphere_obj = d_sphere_obj; S.cone_obj = d_cone_obj; S.mesh_obj = d_mesh_obj;
+    S.n_axis_planes = (int32_t)axis_planes.size(); S.n_gen_planes = (int32_t)gen_planes.size();
+    S.axis_planes = d_axis_planes; S.gen_planes = d_gen_planes;
+    S.plane_obj = d_plane_obj; S.sphere_obj = d_sphere_obj; S.cone_obj = d_cone_obj;
     S.objects = d_objects; S.spheres = d_spheres; S.planes = d_planes; S.cones = d_cones; S.meshes = ctx->d_meshes;
     S.tri_test = ctx->d_tri_test; S.tri_key = ctx->d_tri_key; S.tri_orig = ctx->d_tri_orig;
     S.tri_nrm = d_nrm; S.tri_uv = d_uv; S.tri_material = d_tmat; S.tri_frag = ctx->d_tri_frag; S.tri_sub = ctx->d_tri_sub;

@@ -162,8 +162,7 @@ inline int prepare_meshes(const rt_scene_desc *sc, std::vector<DevMesh> &meshes,
             dm.gate_in_lo[a] = m.box_min[a] + gpad; dm.gate_in_hi[a] = m.box_max[a] - gpad;
         }
         make_gate_tris(m.box_min, m.box_max, gate.data() + 36 * (size_t)i);
-        dm.same_xform = std::memcmp(m.box_to_local, m.to_local, sizeof m.to_local) == 0 ? 1 : 0;
-        dm.pad[0] = dm.pad[1] = 0;
+        dm.same_xform = (!m.boxed || std::memcmp(m.box_to_local, m.to_local, sizeof m.to_local) == 0) ? 1 : 0;
         // World-space bounds for the first rejection test: the padded gate box (boxed meshes) or the
         // padded vertex bounds, mapped to world space in double precision and padded again.
         double lo[3], hi[3], M[12];
@@ -189,17 +188,39 @@ inline int prepare_meshes(const rt_scene_desc *sc, std::vector<DevMesh> &meshes,
     return node_total;
 }
 
-// the plane records find_closest walks: planes that occur in the object list, in plane order
-inline void make_plane_recs(const rt_scene_desc *sc, const std::vector<int32_t> &plane_obj, std::vector<PlaneRec> &recs) {
-    recs.clear();
+// the plane records find_closest walks: planes that occur in the object list, split into
+// axis-aligned and general ones, each array padded with inert records to its group size
+inline void make_plane_recs(const rt_scene_desc *sc, const std::vector<int32_t> &plane_obj, std::vector<AxisPlaneRec> &axis,
+                            std::vector<PlaneRec> &gen) {
+    axis.clear(); gen.clear();
     for (int i = 0; i < sc->n_planes; i++) {
         if (plane_obj[i] < 0) continue;
-        PlaneRec r;
-        for (int a = 0; a < 3; a++) { r.n[a] = sc->planes[i].normal[a]; r.p[a] = sc->planes[i].point[a]; }
-        r.object = plane_obj[i];
-        r.plane = i;
-        recs.push_back(r);
+        const float *n = sc->planes[i].normal, *p = sc->planes[i].point;
+        // lights on the front side of the plane, by a margin of 1e-3 of the scene's scale there
+        uint32_t cannot_shadow = 0;
+        double nlen = std::sqrt((double)n[0] * n[0] + (double)n[1] * n[1] + (double)n[2] * n[2]);
+        for (int l = 0; l < sc->n_lights && l < 32 && nlen > 0 && std::isfinite(nlen); l++) {
+            const float *L = sc->light_pos + 3 * l;
+            double side = 0, scale = 1;
+            for (int a = 0; a < 3; a++) { side += (double)n[a] * ((double)L[a] - p[a]); scale += std::fabs((double)L[a]) + std::fabs((double)p[a]); }
+            if (side / nlen > 1e-3 * scale) cannot_shadow |= 1u << l;
+        }
+        int ax = 0;
+        for (int a = 0; a < 3; a++)
+            if (std::fabs(n[a]) == 1.0f && n[(a + 1) % 3] == 0.0f && n[(a + 2) % 3] == 0.0f) ax = n[a] > 0 ? a + 1 : -(a + 1);
+        if (ax != 0) {
+            AxisPlaneRec r;
+            r.axis = ax; r.coord = p[std::abs(ax) - 1]; r.object = plane_obj[i]; r.cannot_shadow = cannot_shadow;
+            axis.push_back(r);
+        } else {
+            PlaneRec r;
+            for (int a = 0; a < 3; a++) { r.n[a] = n[a]; r.p[a] = p[a]; }
+            r.object = plane_obj[i]; r.cannot_shadow = cannot_shadow;
+            gen.push_back(r);
+        }
     }
+    while (axis.size() % kAxisPlaneGroup) axis.push_back(AxisPlaneRec{0, 0.0f, -1, 0});
+    while (gen.size() % kPlaneGroup) gen.push_back(PlaneRec{{0, 0, 0}, {0, 0, 0}, -1, 0});
 }
 
 }  // namespace rtc

@@ -39,7 +39,8 @@ struct Twin {
     std::vector<uint32_t> tri_key;
     std::vector<int32_t> tri_orig, tri_material, tri_frag, tri_sub;
     std::vector<int32_t> plane_obj, sphere_obj, cone_obj, mesh_obj;
-    std::vector<PlaneRec> plane_recs;
+    std::vector<AxisPlaneRec> axis_planes;
+    std::vector<PlaneRec> gen_planes;
     std::vector<float> tri_pos, tri_nrm, tri_uv, light_pos, light_color;
     std::vector<BvhNode> nodes;
     std::vector<rt_material> materials;
@@ -108,9 +109,11 @@ void *twin_create(const rt_scene_desc *sc, char *errbuf, int errcap) {
     S.n_objects = sc->n_objects; S.n_lights = sc->n_lights;
     S.n_planes = sc->n_planes; S.n_spheres = sc->n_spheres; S.n_cones = sc->n_cones; S.n_meshes = sc->n_meshes;
     kind_to_object(sc, t->plane_obj, t->sphere_obj, t->cone_obj, t->mesh_obj);
-    make_plane_recs(sc, t->plane_obj, t->plane_recs);
-    S.n_plane_recs = (int32_t)t->plane_recs.size(); S.pad0 = 0; S.plane_recs = t->plane_recs.data();
-    S.plane_obj = t->plane_obj.data(); S.sphere_obj = t->sphere_obj.data(); S.cone_obj = t->cone_obj.data(); S.mesh_obj = t->mesh_obj.data();
+    for (int i = 0; i < sc->n_meshes; i++) t->meshes[i].object = t->mesh_obj[i];
+    make_plane_recs(sc, t->plane_obj, t->axis_planes, t->gen_planes);
+    S.n_axis_planes = (int32_t)t->axis_planes.size(); S.n_gen_planes = (int32_t)t->gen_planes.size();
+    S.axis_planes = t->axis_planes.data(); S.gen_planes = t->gen_planes.data();
+    S.plane_obj = t->plane_obj.data(); S.sphere_obj = t->sphere_obj.data(); S.cone_obj = t->cone_obj.data();
     S.objects = t->objects.data(); S.spheres = t->spheres.data(); S.planes = t->planes.data(); S.cones = t->cones.data();
     S.meshes = t->meshes.data(); S.tri_test = t->tri_test.data(); S.tri_key = t->tri_key.data(); S.tri_orig = t->tri_orig.data();
     S.tri_nrm = t->tri_nrm.data(); S.tri_uv = t->tri_uv.data(); S.tri_material = t->tri_material.data();
