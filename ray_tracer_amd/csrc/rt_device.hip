@@ -33,9 +33,10 @@ constexpr int kNumCounters = 10;
 // The packet traversal keeps ONE stack per wave: entries of (node, 64-bit lane mask), three LDS
 // words each.  All lanes write / read the same words (a broadcast access); the values are made
 // scalar again with readfirstlane.
-#ifndef RT_WAVES
-#define RT_WAVES 4  // resident waves per SIMD the render kernel is compiled for (register budget 512 / RT_WAVES)
-#endif
+// Resident waves per SIMD a render kernel variant is compiled for (register budget 512 / waves).
+// The mesh-only variant fits 96 registers without spilling and gains from the fifth wave; the
+// variants with quadrics, textures or secondary rays would spill there.
+constexpr int render_waves(int features, bool count) { return features == F_MESH && !count ? 5 : 4; }
 constexpr int kWavesPerBlock = kBlock / 64;
 constexpr int kStackWords = 3 * kStackDepth;
 struct WaveStack {
@@ -152,7 +153,7 @@ struct RenderArgs {
 // Block b renders local tile b = global tile b * world_size + rank.  Each wave owns an 8x8 pixel
 // quadrant of the 16x16 tile so that its 64 rays are spatially coherent.
 template <int F, bool COUNT>
-__global__ __launch_bounds__(kBlock, RT_WAVES) void k_render(DevScene S, RenderArgs a, float *rgb_tiles, uint8_t *rgb8_tiles,
+__global__ __launch_bounds__(kBlock, render_waves(F, COUNT)) void k_render(DevScene S, RenderArgs a, float *rgb_tiles, uint8_t *rgb8_tiles,
                                                    unsigned long long *counters) {
     RT_WAVE_STACK(stk);
     int tile = blockIdx.x * a.world_size + a.rank;
