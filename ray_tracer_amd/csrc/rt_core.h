@@ -76,9 +76,17 @@ RT_HD int32_t f2i(float f) {
 // ---- wave-level primitives (a "wave" is one lane in the host build)
 RT_HD uint64_t wave_ballot(bool p) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    return __ballot(p);
+    return __builtin_amdgcn_ballot_w64(p);
 #else
     return p ? 1ull : 0ull;
+#endif
+}
+// the lane's bit of a wave-uniform mask, as a per-lane condition (no vector instruction on the device)
+RT_HD bool wave_mask_bit(uint64_t mask) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_inverse_ballot_w64(mask);
+#else
+    return (mask & 1ull) != 0;
 #endif
 }
 RT_HD int32_t wave_uniform(int32_t v) {  // the value of the first active lane, as a scalar
@@ -162,6 +170,12 @@ RT_HD float clamp01(float x) { float m = (x < 0.0f) ? 0.0f : x; return (1.0f < m
 // LBVH node, 64 bytes: the boxes of both children, then the children.  In the packet traversal the
 // node index is wave-uniform, so a node is fetched with ONE scalar load into SGPRs and its twelve
 // bounds feed the per-lane slab tests as scalar operands.
+// Every mesh stores its nodes eight times, once per ray-direction octant o (bit a set: direction
+// component a negative): variant o holds, in the lo* / hi* slots, the NEAR / FAR face of each box for
+// that octant (variant 0 is the plain lo / hi node).  A wave whose rays share an octant reads the
+// matching variant and needs no per-lane min / max to order the slab distances.  Variant o of node i
+// of a mesh with n nodes is nodes[node_offset + o * n + i].
+constexpr int kOctants = 8;
 struct BvhNode {
     float lo0[3], hi0[3];
     float lo1[3], hi1[3];
@@ -607,27 +621,49 @@ RT_HD void bvh_closest_packet(const DevScene &S, const MeshHead &m, v3 o, v3 d, 
     // reciprocal keeps the sign logic (the ray then counts as parallel to that slab).
     v3 inv = V3(safe_rcp(d.x), safe_rcp(d.y), safe_rcp(d.z));
     v3 oi = o * inv;
-    const uint64_t my_bit = 1ull << wave_lane();
+    // When all participating rays point into the same octant, which face of a box is the near one
+    // is a wave-uniform fact: the wave reads the node variant stored for that octant and the per-lane
+    // min / max pairs of the slab test disappear (same values, same decisions: t(lo) <= t(hi) for a
+    // positive reciprocal, the reverse for a negative one).
+    uint64_t wants = wave_ballot(want);
+    uint64_t negx = wave_ballot(want & (inv.x < 0)), negy = wave_ballot(want & (inv.y < 0)), negz = wave_ballot(want & (inv.z < 0));
+    const bool one_octant = (negx == 0 || negx == wants) & (negy == 0 || negy == wants) & (negz == 0 || negz == wants);
+    if (one_octant) nodes += (size_t)((negx != 0 ? 1 : 0) | (negy != 0 ? 2 : 0) | (negz != 0 ? 4 : 0)) * (size_t)(m.tri_count - 1);
     int sp = 0;  // wave-uniform stack height
     int32_t cur = m.tri_count == 1 ? ~0 : 0;
     bool in = want;
     for (;;) {
         if (cur >= 0) {
-            const BvhNode &nd = nodes[cur];
+            // the whole node in scalar registers first: bounds 0-11 (lo0 hi0 lo1 hi1), children 12-13
+            u32x16 nd = load_u32x16(nodes + cur);
+            pin_scalar(nd);
             if (COUNT && in) wk.box += 2;
-            float n0, n1;
-            bool h0 = in & slab_fused(nd.lo0[0], nd.lo0[1], nd.lo0[2], nd.hi0[0], nd.hi0[1], nd.hi0[2], inv, oi, best.t, n0);
-            bool h1 = in & slab_fused(nd.lo1[0], nd.lo1[1], nd.lo1[2], nd.hi1[0], nd.hi1[1], nd.hi1[2], inv, oi, best.t, n1);
-            uint64_t b0 = wave_ballot(h0), b1 = wave_ballot(h1);
-            // when both children are needed: first the one that more lanes would enter first
-            uint64_t pref1 = wave_ballot(h1 & (!h0 | (n1 < n0)));
-            bool both = (b0 != 0) & (b1 != 0);
-            bool second_first = both ? 2 * popc64(pref1) > popc64(b0 | b1) : b0 == 0;
-            int32_t c0 = nd.c0, c1 = nd.c1;
-            if (both) stk.put(sp++, second_first ? c0 : c1, second_first ? b0 : b1);
+            // a lane that is not in the visit gets an empty interval: its tests below fail by themselves
+            float tm = in ? best.t : -1.0f;
+            // (the ballots are taken inside each branch so that only wave-uniform values leave it)
+            uint64_t b0, b1, nearer1;
+            if (one_octant) {
+                float n0 = fmaxf(fmaxf(fma_(u2f(nd[0]), inv.x, -oi.x), fma_(u2f(nd[1]), inv.y, -oi.y)), fmaxf(fma_(u2f(nd[2]), inv.z, -oi.z), 0.0f));
+                float f0 = fminf(fminf(fma_(u2f(nd[3]), inv.x, -oi.x), fma_(u2f(nd[4]), inv.y, -oi.y)), fminf(fma_(u2f(nd[5]), inv.z, -oi.z), tm));
+                float n1 = fmaxf(fmaxf(fma_(u2f(nd[6]), inv.x, -oi.x), fma_(u2f(nd[7]), inv.y, -oi.y)), fmaxf(fma_(u2f(nd[8]), inv.z, -oi.z), 0.0f));
+                float f1 = fminf(fminf(fma_(u2f(nd[9]), inv.x, -oi.x), fma_(u2f(nd[10]), inv.y, -oi.y)), fminf(fma_(u2f(nd[11]), inv.z, -oi.z), tm));
+                b0 = wave_ballot(n0 <= f0); b1 = wave_ballot(n1 <= f1); nearer1 = wave_ballot(n1 < n0);
+            } else {
+                float n0, n1;
+                bool h0 = slab_fused(u2f(nd[0]), u2f(nd[1]), u2f(nd[2]), u2f(nd[3]), u2f(nd[4]), u2f(nd[5]), inv, oi, tm, n0);
+                bool h1 = slab_fused(u2f(nd[6]), u2f(nd[7]), u2f(nd[8]), u2f(nd[9]), u2f(nd[10]), u2f(nd[11]), inv, oi, tm, n1);
+                b0 = wave_ballot(h0); b1 = wave_ballot(h1); nearer1 = wave_ballot(n1 < n0);
+            }
             if ((b0 | b1) != 0) {
+                int32_t c0 = (int32_t)nd[12], c1 = (int32_t)nd[13];
+                bool second_first = b0 == 0;
+                if (b0 != 0 && b1 != 0) {
+                    // both children are needed: first the one that more lanes would enter first
+                    second_first = 2 * (popc64(b1 & ~b0) + popc64(nearer1 & b0 & b1)) > popc64(b0 | b1);
+                    stk.put(sp++, second_first ? c0 : c1, second_first ? b0 : b1);
+                }
                 cur = second_first ? c1 : c0;
-                in = second_first ? h1 : h0;
+                in = wave_mask_bit(second_first ? b1 : b0);
                 continue;
             }
         } else {
@@ -637,7 +673,7 @@ RT_HD void bvh_closest_packet(const DevScene &S, const MeshHead &m, v3 o, v3 d, 
         if (sp == 0) break;
         uint64_t mask;
         stk.get(--sp, cur, mask);
-        in = (mask & my_bit) != 0;
+        in = wave_mask_bit(mask);
     }
 }
 

@@ -152,6 +152,14 @@ struct RenderArgs {
 
 // Block b renders local tile b = global tile b * world_size + rank.  Each wave owns an 8x8 pixel
 // quadrant of the 16x16 tile so that its 64 rays are spatially coherent.
+// copies of the fitted tree for the ray-direction octants 1..7 (variant 0 is what k_fit wrote)
+__global__ void k_octant_variants(BvhNode *nodes, int n) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * (kOctants - 1)) return;
+    int o = 1 + idx / n, i = idx % n;
+    nodes[(size_t)o * n + i] = lbvh_octant_variant(nodes[i], o);
+}
+
 template <int F, bool COUNT>
 __global__ __launch_bounds__(kBlock, render_waves(F, COUNT)) void k_render(DevScene S, RenderArgs a, float *rgb_tiles, uint8_t *rgb8_tiles,
                                                    unsigned long long *counters) {
@@ -501,6 +509,8 @@ extern "C" int rt_build_accel(rt_ctx *ctx) {
             hipLaunchKernelGGL(k_fit, dim3(1), dim3(1024), 0, ctx->stream, n, d_c0, d_c1,
                                ctx->d_tri_test + 3 * (size_t)m.tri_offset, ctx->mesh_build[i].pad, d_done, d_lo, d_hi, d_height,
                                ctx->d_nodes + m.node_offset, d_root + i);
+            int nv = (n - 1) * (kOctants - 1);
+            hipLaunchKernelGGL(k_octant_variants, dim3((nv + 255) / 256), blk, 0, ctx->stream, ctx->d_nodes + m.node_offset, n - 1);
         }
     }
     (void)hipEventRecord(ctx->ev1, ctx->stream);

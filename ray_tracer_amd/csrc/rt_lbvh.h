@@ -125,4 +125,17 @@ RT_HD int lbvh_fit_node(int i, int pass, const int32_t *c0s, const int32_t *c1s,
     return 1;
 }
 
+// The variant of a plain node for ray-direction octant o: near faces in the lo slots, far faces in
+// the hi slots (bit a of o set: direction component a negative, so the near face is the hi bound).
+RT_HD BvhNode lbvh_octant_variant(const BvhNode &n, int o) {
+    BvhNode v = n;
+    for (int a = 0; a < 3; a++) {
+        if ((o >> a) & 1) {
+            v.lo0[a] = n.hi0[a]; v.hi0[a] = n.lo0[a];
+            v.lo1[a] = n.hi1[a]; v.hi1[a] = n.lo1[a];
+        }
+    }
+    return v;
+}
+
 }  // namespace rtc

@@ -139,7 +139,7 @@ inline int prepare_meshes(const rt_scene_desc *sc, std::vector<DevMesh> &meshes,
         dm.node_offset = node_total; dm.gate_tri_offset = 12 * i;
         dm.pad[0] = dm.pad[1] = 0;
         mb.node_offset = node_total;
-        node_total += std::max(m.tri_count - 1, 0);
+        node_total += kOctants * std::max(m.tri_count - 1, 0);  // one copy of the tree per ray-direction octant
         float maxabs = 0;
         for (int a = 0; a < 3; a++) { mb.lo[a] = INFINITY; mb.hi[a] = -INFINITY; }
         for (int t = 0; t < m.tri_count; t++) {

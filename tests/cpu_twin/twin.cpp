@@ -151,6 +151,9 @@ int twin_build_accel(void *h) {
                     left++;
             if (!left) break;
         }
+        for (int o = 1; o < kOctants; o++)
+            for (int i = 0; i < n - 1; i++)
+                t->nodes[m.node_offset + (size_t)o * (n - 1) + i] = lbvh_octant_variant(t->nodes[m.node_offset + i], o);
         t->build[mi].height = height[0];
         t->bvh_max_depth = std::max(t->bvh_max_depth, height[0]);
     }
