@@ -36,7 +36,7 @@ WORKLOADS = {
 
 def cpu_baseline(preset, width, height, mode, grid_m, max_depth, budget_blocks=None):
     """Times the CPU oracle on a bounded sample of the same frame: 8x8-pixel blocks on a regular
-    64-pixel lattice (1/64 of the pixels, all taps), traced with OpenMP over all allowed cores."""
+    24-pixel lattice (1/9 of the pixels, all taps), traced with OpenMP over all allowed cores."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import numpy as np
     import oracle_lib as O
@@ -46,7 +46,7 @@ def cpu_baseline(preset, width, height, mode, grid_m, max_depth, budget_blocks=N
     L.orc_set_threads(threads)
     scene = O.Scene(preset)
     os_, ds_ = [], []
-    step, blk = 64, 8
+    step, blk = 24, 8
     for y0 in range(0, height - blk + 1, step):
         for x0 in range(0, width - blk + 1, step):
             o, d, _ = O.camera_rays(width, height, 90.0, mode, grid_m, rect=(x0, y0, x0 + blk, y0 + blk))
@@ -58,7 +58,7 @@ def cpu_baseline(preset, width, height, mode, grid_m, max_depth, budget_blocks=N
     dt = time.perf_counter() - t0
     total = int(rays.sum())
     return {"value": total / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
-            "sample": f"8x8-pixel blocks every 64 px of the {width}x{height} frame "
+            "sample": f"8x8-pixel blocks every 24 px of the {width}x{height} frame "
                       f"({len(o)} primary rays, {total} rays, {dt:.1f} s)"}
 
 
