@@ -196,6 +196,15 @@ const char *rt_last_error(const rt_ctx *ctx);
  * copies the description to the GPU.  The caller keeps ownership of every pointer. */
 int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *scene);
 
+/* A new frame of the same geometry: `scene` must have the triangle positions / normals / uvs, mesh
+ * triangle ranges and object / light / texture counts of the uploaded scene; transformations (of spheres, cones,
+ * meshes and their boxes), planes, materials, lights and the ambient term may differ.  Only those small
+ * tables are copied; triangles, textures and the LBVHs (built in each mesh's own space) are kept, so a
+ * moving object costs no rebuild.  The reference renders one still image; its .gitignore:3-4 (frames/,
+ * *.mp4) shows the frame loop this serves, which with the reference means re-running main() per frame
+ * (main.cpp:1212-1288). */
+int rt_scene_update(rt_ctx *ctx, const rt_scene_desc *scene);
+
 /* Builds one Morton-code LBVH per mesh on the GPU (replaces the linear fragment scan of
  * Mesh::intersect, main.cpp:534-539, with identical closest-hit results).  Idempotent. */
 int rt_build_accel(rt_ctx *ctx);

@@ -121,7 +121,7 @@ HIT_DTYPE = np.dtype([("hit", "i4"), ("object", "i4"), ("frag", "i4"), ("sub", "
                       ("point", "f4", 3), ("uv", "f4", 2)])
 
 # every symbol include/rt_amd.h declares
-ABI_SYMBOLS = ["rt_context_create", "rt_context_destroy", "rt_last_error", "rt_scene_upload",
+ABI_SYMBOLS = ["rt_context_create", "rt_context_destroy", "rt_last_error", "rt_scene_upload", "rt_scene_update",
                "rt_build_accel", "rt_render", "rt_shard_tiles", "rt_render_shard_device",
                "rt_untile_device", "rt_sync", "rt_stream", "rt_set_stream", "rt_trace_rays", "rt_intersect_object",
                "rt_get_counters", "rt_reset_counters", "rt_debug_copy_bvh"]
@@ -151,6 +151,7 @@ def amd():
         L.rt_last_error.argtypes = [vp]
         L.rt_last_error.restype = C.c_char_p
         L.rt_scene_upload.argtypes = [vp, C.POINTER(SceneDesc)]
+        L.rt_scene_update.argtypes = [vp, C.POINTER(SceneDesc)]
         L.rt_build_accel.argtypes = [vp]
         L.rt_render.argtypes = [vp, C.POINTER(RenderParams), vp, vp]
         L.rt_shard_tiles.argtypes = [C.POINTER(RenderParams), C.POINTER(i32), C.POINTER(i32)]
@@ -367,6 +368,11 @@ class Context:
         self._check(self.L.rt_scene_upload(self.h, desc), "rt_scene_upload")
         if build:
             self.build_accel()
+
+    def update(self, scene):
+        """New placement / materials / lights of the uploaded geometry; keeps triangles, textures and LBVHs."""
+        desc = scene.flatten() if isinstance(scene, HostScene) else scene
+        self._check(self.L.rt_scene_update(self.h, desc), "rt_scene_update")
 
     def build_accel(self):
         self._check(self.L.rt_build_accel(self.h), "rt_build_accel")

@@ -2,7 +2,10 @@
 // builds a scene, renders it and writes an ASCII PPM; the scene, size and sampling are selectable:
 //   rt_main [out.ppm] [--preset shells|analytic|teapot|teapot_head|textured] [--size WxH]
 //           [--mode 1spp|aa9|gridN] [--depth D] [--assets DIR] [--brute] [--p6] [--device N]
+//           [--frames N [--spin DEGREES]]
 // Defaults reproduce the reference: preset shells, 1024x768, 1 spp, ./result.ppm.
+// --frames N renders N frames, turning every mesh by DEGREES (default 360 / N) about its own y axis
+// per frame, and writes out_0000.ppm ...; the geometry is uploaded and its LBVHs are built once.
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -18,6 +21,8 @@ int main(int argc, const char *argv[]) {
     std::string out = "./result.ppm", preset = "shells", assets = "assets";
     int width = 1024, height = 768, mode = RT_MODE_REF_1SPP, grid = 1, depth = 8, device = 0, accel = RT_ACCEL_LBVH;
     bool p6 = false;
+    int frames = 1;
+    float spin = 0;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
         auto next = [&]() -> const char * { return i + 1 < argc ? argv[++i] : ""; };
@@ -34,6 +39,8 @@ int main(int argc, const char *argv[]) {
         else if (a == "--device") device = std::atoi(next());
         else if (a == "--brute") accel = RT_ACCEL_BRUTE;
         else if (a == "--p6") p6 = true;
+        else if (a == "--frames") frames = std::atoi(next());
+        else if (a == "--spin") spin = (float)std::atof(next());
         else if (a.rfind("--", 0) == 0) { std::cerr << "unknown option " << a << "\n"; return 2; }
         else out = a;
     }
@@ -50,17 +57,42 @@ int main(int argc, const char *argv[]) {
         p.width = width; p.height = height; p.fov = 90; p.mode = mode; p.grid_m = grid; p.max_depth = depth;
         p.accel = accel; p.rank = 0; p.world_size = 1;
         std::vector<uint8_t> rgb8(3 * (size_t)width * height);
-        renderer.render(p, nullptr, rgb8.data());
-        rt_counters c = renderer.counters();
+        if (frames < 1) frames = 1;
+        if (spin == 0) spin = 360.0f / frames;
+        // the meshes (behind their Box gates) and their poses in frame 0
+        std::vector<Object *> movers;
+        std::vector<mat4> base;
+        for (Object *o : holder.scene.objects) {
+            Object *target = o;
+            if (Box *bx = dynamic_cast<Box *>(o)) target = bx->obj;
+            if (dynamic_cast<Mesh *>(target)) { movers.push_back(target); base.push_back(target->transformation()); }
+            if (target != o) { movers.push_back(o); base.push_back(o->transformation()); }
+        }
+        for (int f = 0; f < frames; f++) {
+            if (f > 0) {
+                float angle = (float)(spin * f * 3.14159265358979323846 / 180.0);
+                for (size_t k = 0; k < movers.size(); k++) movers[k]->setTransformation(rotate(base[k], angle, vec3(0, 1, 0)));
+                renderer.update(holder.scene);
+            }
+            renderer.render(p, nullptr, rgb8.data());
+            rt_counters c = renderer.counters();
+            unsigned long long rays = c.rays_primary + c.rays_shadow + c.rays_secondary;
+            std::cout << "frame " << f << ": trace kernel " << c.last_trace_ms << " ms, " << rays << " rays, " << rays / (c.last_trace_ms * 1e3)
+                      << " Mrays/s; LBVH build " << c.last_build_ms << " ms (once)" << std::endl;
+            std::string path = out;
+            if (frames > 1) {
+                char tag[16];
+                std::snprintf(tag, sizeof tag, "_%04d", f);
+                size_t dot = out.rfind('.');
+                path = dot == std::string::npos ? out + tag : out.substr(0, dot) + tag + out.substr(dot);
+            }
+            Image image(width, height);
+            image.setPixels8(rgb8.data());
+            if (p6) image.writeImageBinary(path.c_str()); else image.writeImage(path.c_str());
+        }
         double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         std::cout << "It took " << secs << " seconds to render the image." << std::endl;
-        std::cout << "I could render at " << 1.0 / secs << " frames per second." << std::endl;
-        unsigned long long rays = c.rays_primary + c.rays_shadow + c.rays_secondary;
-        std::cout << "trace kernel: " << c.last_trace_ms << " ms, " << rays << " rays, " << rays / (c.last_trace_ms * 1e3) << " Mrays/s; LBVH build "
-                  << c.last_build_ms << " ms" << std::endl;
-        Image image(width, height);
-        image.setPixels8(rgb8.data());
-        if (p6) image.writeImageBinary(out.c_str()); else image.writeImage(out.c_str());
+        std::cout << "I could render at " << frames / secs << " frames per second." << std::endl;
     } catch (const std::exception &e) {
         std::cerr << "error: " << e.what() << std::endl;
         return 1;

@@ -280,6 +280,12 @@ void Renderer::upload(const Scene &scene) {
     if (rt_scene_upload(ctx, &fs.desc) != RT_OK) throw std::runtime_error(std::string("rt_scene_upload: ") + rt_last_error(ctx));
     if (rt_build_accel(ctx) != RT_OK) throw std::runtime_error(std::string("rt_build_accel: ") + rt_last_error(ctx));
 }
+void Renderer::update(const Scene &scene) {
+    FlatScene fs;
+    std::string err;
+    if (!scene.flatten(fs, err)) throw std::runtime_error("flatten: " + err);
+    if (rt_scene_update(ctx, &fs.desc) != RT_OK) throw std::runtime_error(std::string("rt_scene_update: ") + rt_last_error(ctx));
+}
 void Renderer::render(const rt_render_params &p, float *rgb_linear, uint8_t *rgb8) {
     if (rt_render(ctx, &p, rgb_linear, rgb8) != RT_OK) throw std::runtime_error(std::string("rt_render: ") + rt_last_error(ctx));
 }

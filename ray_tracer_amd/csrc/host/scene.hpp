@@ -251,6 +251,7 @@ class Renderer {
     Renderer &operator=(const Renderer &) = delete;
     rt_ctx *handle() { return ctx; }
     void upload(const Scene &scene);  // flatten + rt_scene_upload + rt_build_accel; throws std::runtime_error
+    void update(const Scene &scene);  // same geometry, new transformations / materials / lights: rt_scene_update
     void render(const rt_render_params &p, float *rgb_linear, uint8_t *rgb8);
     void trace(const std::vector<Ray> &rays, int max_depth, std::vector<Hit> *hits, std::vector<vec3> *radiance,
                const Scene &scene);

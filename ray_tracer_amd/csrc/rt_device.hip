@@ -247,7 +247,8 @@ struct rt_ctx {
     DevScene S{};
     std::vector<DevMesh> meshes;
     std::vector<MeshBuild> mesh_build;
-    int n_triangles = 0, n_meshes = 0, n_nodes = 0;
+    int n_triangles = 0, n_meshes = 0, n_nodes = 0, n_textures = 0, n_materials = 0;
+    std::vector<int32_t> mesh_ranges;  // (tri_offset, tri_count) of every uploaded mesh
     // device arrays the build writes
     float *d_tri_pos = nullptr;
     f4 *d_tri_test = nullptr;
@@ -411,8 +412,13 @@ extern "C" int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *sc) {
     make_plane_recs(sc, plane_obj, axis_planes, gen_planes);
     AxisPlaneRec *d_axis_planes;
     PlaneRec *d_gen_planes;
-    if ((rc = dev_alloc(ctx, &d_axis_planes, axis_planes.size(), axis_planes.data()))) return rc;
-    if ((rc = dev_alloc(ctx, &d_gen_planes, gen_planes.size(), gen_planes.data()))) return rc;
+    // sized for any split of the planes into the two classes, so that rt_scene_update can re-partition them
+    size_t cap_axis = ((size_t)sc->n_planes + kAxisPlaneGroup - 1) / kAxisPlaneGroup * kAxisPlaneGroup;
+    size_t cap_gen = ((size_t)sc->n_planes + kPlaneGroup - 1) / kPlaneGroup * kPlaneGroup;
+    if ((rc = dev_alloc(ctx, &d_axis_planes, cap_axis, (const void *)nullptr))) return rc;
+    if ((rc = dev_alloc(ctx, &d_gen_planes, cap_gen, (const void *)nullptr))) return rc;
+    if (!axis_planes.empty()) RT_HIP(hipMemcpyAsync(d_axis_planes, axis_planes.data(), axis_planes.size() * sizeof(AxisPlaneRec), hipMemcpyHostToDevice, ctx->stream));
+    if (!gen_planes.empty()) RT_HIP(hipMemcpyAsync(d_gen_planes, gen_planes.data(), gen_planes.size() * sizeof(PlaneRec), hipMemcpyHostToDevice, ctx->stream));
 
     // meshes: bounds, padding, gate triangles, node ranges
     ctx->n_meshes = sc->n_meshes;
@@ -452,6 +458,75 @@ extern "C" int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *sc) {
     ctx->features = scene_features(sc);
     ctx->uploaded = true;
     ctx->built = false;
+    ctx->n_textures = sc->n_textures;
+    ctx->n_materials = sc->n_materials;
+    ctx->mesh_ranges.clear();
+    for (int i = 0; i < sc->n_meshes; i++) { ctx->mesh_ranges.push_back(sc->meshes[i].tri_offset); ctx->mesh_ranges.push_back(sc->meshes[i].tri_count); }
+    return RT_OK;
+}
+
+template <typename T>
+static int dev_update(rt_ctx *ctx, const T *dst, const void *src, size_t count) {
+    if (count) RT_HIP(hipMemcpyAsync(const_cast<T *>(dst), src, count * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+    return RT_OK;
+}
+
+extern "C" int rt_scene_update(rt_ctx *ctx, const rt_scene_desc *sc) {
+    if (!ctx || !sc) return RT_ERR_INVALID;
+    if (!ctx->uploaded) return fail(ctx, RT_ERR_STATE, "rt_scene_update before rt_scene_upload");
+    RT_HIP(hipSetDevice(ctx->device));
+    std::string bad = validate_scene(sc);
+    if (!bad.empty()) return fail(ctx, RT_ERR_INVALID, bad);
+    DevScene &S = ctx->S;
+    bool same = sc->n_objects == S.n_objects && sc->n_lights == S.n_lights && sc->n_planes == S.n_planes &&
+                sc->n_spheres == S.n_spheres && sc->n_cones == S.n_cones && sc->n_meshes == S.n_meshes &&
+                sc->n_triangles == ctx->n_triangles && sc->n_textures == ctx->n_textures;
+    for (int i = 0; same && i < sc->n_meshes; i++)
+        same = sc->meshes[i].tri_offset == ctx->mesh_ranges[2 * i] && sc->meshes[i].tri_count == ctx->mesh_ranges[2 * i + 1];
+    if (!same) return fail(ctx, RT_ERR_INVALID, "rt_scene_update: counts or mesh triangle ranges differ from the uploaded scene");
+    RT_HIP(hipStreamSynchronize(ctx->stream));  // no frame in flight may see half of the new tables
+
+    int rc;
+    if ((rc = dev_update(ctx, S.objects, sc->objects, sc->n_objects))) return rc;
+    if ((rc = dev_update(ctx, S.spheres, sc->spheres, sc->n_spheres))) return rc;
+    if ((rc = dev_update(ctx, S.planes, sc->planes, sc->n_planes))) return rc;
+    if ((rc = dev_update(ctx, S.cones, sc->cones, sc->n_cones))) return rc;
+    if (sc->n_materials > ctx->n_materials) {  // more distinct materials than the table holds: a larger table
+        rt_material *d_materials;
+        if ((rc = dev_alloc(ctx, &d_materials, sc->n_materials, (const void *)nullptr))) return rc;
+        S.materials = d_materials;
+        ctx->n_materials = sc->n_materials;
+    }
+    if ((rc = dev_update(ctx, S.materials, sc->materials, sc->n_materials))) return rc;
+    if ((rc = dev_update(ctx, S.tri_material, sc->tri_material, (size_t)sc->n_triangles))) return rc;  // indices into the new table
+    if ((rc = dev_update(ctx, S.light_pos, sc->light_pos, 3 * (size_t)sc->n_lights))) return rc;
+    if ((rc = dev_update(ctx, S.light_color, sc->light_color, 3 * (size_t)sc->n_lights))) return rc;
+    std::vector<int32_t> plane_obj, sphere_obj, cone_obj, mesh_obj;
+    kind_to_object(sc, plane_obj, sphere_obj, cone_obj, mesh_obj);
+    if ((rc = dev_update(ctx, S.plane_obj, plane_obj.data(), plane_obj.size()))) return rc;
+    if ((rc = dev_update(ctx, S.sphere_obj, sphere_obj.data(), sphere_obj.size()))) return rc;
+    if ((rc = dev_update(ctx, S.cone_obj, cone_obj.data(), cone_obj.size()))) return rc;
+    std::vector<AxisPlaneRec> axis_planes;
+    std::vector<PlaneRec> gen_planes;
+    make_plane_recs(sc, plane_obj, axis_planes, gen_planes);
+    if ((rc = dev_update(ctx, S.axis_planes, axis_planes.data(), axis_planes.size()))) return rc;
+    if ((rc = dev_update(ctx, S.gen_planes, gen_planes.data(), gen_planes.size()))) return rc;
+    S.n_axis_planes = (int32_t)axis_planes.size(); S.n_gen_planes = (int32_t)gen_planes.size();
+    // mesh records: new maps, gate boxes and world bounds; triangle and node ranges are unchanged
+    std::vector<DevMesh> meshes;
+    std::vector<MeshBuild> build;
+    std::vector<f4> gate;
+    prepare_meshes(sc, meshes, build, gate);
+    for (int i = 0; i < sc->n_meshes; i++) {
+        meshes[i].object = mesh_obj[i];
+        if (meshes[i].node_offset != ctx->meshes[i].node_offset) return fail(ctx, RT_ERR_STATE, "rt_scene_update: node layout changed");
+    }
+    ctx->meshes = meshes;
+    if ((rc = dev_update(ctx, S.gate_tri, gate.data(), gate.size()))) return rc;
+    if ((rc = dev_update(ctx, S.meshes, ctx->meshes.data(), ctx->meshes.size()))) return rc;
+    for (int a = 0; a < 3; a++) S.ambient[a] = sc->ambient[a];
+    RT_HIP(hipStreamSynchronize(ctx->stream));  // the caller's arrays may go away after return
+    ctx->features = scene_features(sc);
     return RT_OK;
 }
 

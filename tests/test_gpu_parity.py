@@ -226,3 +226,49 @@ def test_empty_and_tiny_meshes_on_gpu():
         assert list(hits["hit"]) == want
         assert np.isfinite(rad).all()
         ctx.close()
+
+
+def _posed_room(angle, light_y, reflective=False):
+    """The teapot room with the teapot turned by `angle` about y and the first light at height light_y."""
+    hs = rt.HostScene()
+    red = rt.Material(ambient=(0.01, 0.02, 0.02), diffuse=(1.0, 0.2, 0.2), specular=0.5, shininess=10.0)
+    wall = rt.Material(reflectiveness=0.4) if reflective else rt.Material()
+    M = rt.rotate(angle, (0, 1, 0), rt.translate((0, 1, 10)))
+    hs.add_mesh_obj(os.path.join(rt.ASSETS, "teapot.obj"), M, red, boxed=True, flip_normals=True)
+    hs.add_plane((0, -3, 0), (0, 1, 0), wall)
+    hs.add_plane((0, 1, 30), (0, 0, -1), rt.Material())
+    hs.add_plane((0, 2, 40), (0.3, 0.1, -1), rt.Material())  # a general (not axis-aligned) plane
+    hs.add_light((10, light_y, -7), 0.5)
+    hs.add_light((2, 7, 1), 0.2)
+    return hs
+
+
+def test_scene_update_equals_fresh_upload():
+    """rt_scene_update (new pose, lights, materials; same triangles) renders exactly what a fresh upload
+    of the new scene renders, without rebuilding the LBVH."""
+    ctx = rt.Context(0)
+    ctx.upload(_posed_room(0.0, 16))
+    first, _ = ctx.render(160, 96, mode=rt.MODE_GRID, grid_m=2)
+    build_ms = ctx.counters().last_build_ms
+    for angle, ly, refl in [(0.7, 16, False), (2.1, 9, False), (3.5, 12, True)]:
+        scene = _posed_room(angle, ly, refl)
+        ctx.update(scene)
+        got, got8 = ctx.render(160, 96, mode=rt.MODE_GRID, grid_m=2)
+        assert ctx.counters().last_build_ms == build_ms  # no rebuild happened
+        fresh = rt.Context(0)
+        fresh.upload(scene)
+        want, want8 = fresh.render(160, 96, mode=rt.MODE_GRID, grid_m=2)
+        fresh.close()
+        assert np.array_equal(got, want, equal_nan=True) and np.array_equal(got8, want8)
+        assert not np.array_equal(got, first)
+    # geometry that does not match the upload is refused
+    other = rt.HostScene()
+    other.add_plane((0, -3, 0), (0, 1, 0), rt.Material())
+    other.add_light((0, 5, 0), 1.0)
+    with pytest.raises(rt.RtError, match="differ"):
+        ctx.update(other)
+    ctx.close()
+    empty = rt.Context(0)
+    with pytest.raises(rt.RtError, match="before rt_scene_upload"):
+        empty.update(_posed_room(0.0, 16))
+    empty.close()
