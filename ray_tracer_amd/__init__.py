@@ -266,6 +266,13 @@ def write_ppm(path, rgb8, binary=False):
     host().rth_write_ppm(path.encode(), w, h, _ptr(rgb8), 1 if binary else 0)
 
 
+def write_png(path, rgb8):
+    rgb8 = np.ascontiguousarray(rgb8, dtype=np.uint8)
+    h, w = rgb8.shape[:2]
+    if host().rth_write_ppm(path.encode(), w, h, _ptr(rgb8), 2) != 0:
+        raise RtError(f"cannot write {path}")
+
+
 class HostScene:
     """A scene built through the C++ object API (host side only, no GPU needed)."""
 

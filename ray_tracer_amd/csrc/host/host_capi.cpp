@@ -186,10 +186,11 @@ int rth_decode_png(const char *path, unsigned *w, unsigned *h, uint8_t *out, siz
     return 0;
 }
 
-// Image sink: quantised frame -> ASCII P3 (binary = 0) or P6 (binary = 1)
+// Image sink: quantised frame -> ASCII P3 (binary = 0), P6 (binary = 1) or PNG (binary = 2)
 int rth_write_ppm(const char *path, int w, int h, const uint8_t *rgb8, int binary) {
     Image im(w, h);
     im.setPixels8(rgb8);
+    if (binary == 2) return im.writeImagePNG(path) ? 0 : -1;
     if (binary) im.writeImageBinary(path); else im.writeImage(path);
     return 0;
 }

@@ -3,7 +3,8 @@
 //   rt_main [out.ppm] [--preset shells|analytic|teapot|teapot_head|textured] [--size WxH]
 //           [--mode 1spp|aa9|gridN] [--depth D] [--assets DIR] [--brute] [--p6] [--device N]
 //           [--frames N [--spin DEGREES]]
-// Defaults reproduce the reference: preset shells, 1024x768, 1 spp, ./result.ppm.
+// Defaults reproduce the reference: preset shells, 1024x768, 1 spp, ./result.ppm.  An output name ending
+// in .png is written as an 8-bit RGB PNG.
 // --frames N renders N frames, turning every mesh by DEGREES (default 360 / N) about its own y axis
 // per frame, and writes out_0000.ppm ...; the geometry is uploaded and its LBVHs are built once.
 #include <chrono>
@@ -88,7 +89,10 @@ int main(int argc, const char *argv[]) {
             }
             Image image(width, height);
             image.setPixels8(rgb8.data());
-            if (p6) image.writeImageBinary(path.c_str()); else image.writeImage(path.c_str());
+            bool png = path.size() > 4 && path.compare(path.size() - 4, 4, ".png") == 0;
+            if (png) { if (!image.writeImagePNG(path.c_str())) throw std::runtime_error("cannot write " + path); }
+            else if (p6) image.writeImageBinary(path.c_str());
+            else image.writeImage(path.c_str());
         }
         double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         std::cout << "It took " << secs << " seconds to render the image." << std::endl;

@@ -235,6 +235,7 @@ class Image {
     void setPixels8(const uint8_t *rgb8);   // a whole frame as the renderer delivers it
     void writeImage(const char *path) const;  // ASCII P3, byte-for-byte the reference's layout
     void writeImageBinary(const char *path) const;  // P6, same pixels
+    bool writeImagePNG(const char *path) const;     // 8-bit RGB PNG, same pixels
     int w() const { return width; }
     int h() const { return height; }
     const std::vector<int> &pixels() const { return data; }

@@ -162,3 +162,33 @@ def test_tiling_roundtrip():
         for world in (1, 2, 3, 8):
             shards = np.stack([tiling.shard_from_frame(frame, r, world) for r in range(world)])
             assert np.array_equal(tiling.frame_from_shards(shards, w, h), frame)
+
+
+def test_png_writer_round_trips_through_the_decoder(tmp_path):
+    """The PNG sink writes the pixels it was given: read back with the renderer's own PNG decoder and, as
+    an independent check of the container, with zlib by hand."""
+    import struct
+    import zlib
+    rng = np.random.default_rng(5)
+    for h, w in [(1, 1), (7, 13), (64, 48)]:
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        path = str(tmp_path / f"f_{h}x{w}.png")
+        rt.write_png(path, img)
+        back = rt.decode_png(path)
+        assert back.shape == (h, w, 4) and np.array_equal(back[..., :3], img) and (back[..., 3] == 255).all()
+        blob = open(path, "rb").read()
+        assert blob[:8] == b"\x89PNG\r\n\x1a\n"
+        pos, idat, kinds = 8, b"", []
+        while pos < len(blob):
+            n, kind = struct.unpack(">I4s", blob[pos:pos + 8])
+            body = blob[pos + 8:pos + 8 + n]
+            assert struct.unpack(">I", blob[pos + 8 + n:pos + 12 + n])[0] == zlib.crc32(kind + body)
+            kinds.append(kind)
+            if kind == b"IHDR":
+                assert struct.unpack(">IIBBBBB", body) == (w, h, 8, 2, 0, 0, 0)
+            if kind == b"IDAT":
+                idat += body
+            pos += 12 + n
+        assert kinds[0] == b"IHDR" and kinds[-1] == b"IEND"
+        raw = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(h, 1 + 3 * w)
+        assert (raw[:, 0] == 0).all() and np.array_equal(raw[:, 1:].reshape(h, w, 3), img)
