@@ -69,6 +69,7 @@ int main(int argc, const char *argv[]) {
             if (dynamic_cast<Mesh *>(target)) { movers.push_back(target); base.push_back(target->transformation()); }
             if (target != o) { movers.push_back(o); base.push_back(o->transformation()); }
         }
+        unsigned long long rays_before = 0;
         for (int f = 0; f < frames; f++) {
             if (f > 0) {
                 float angle = (float)(spin * f * 3.14159265358979323846 / 180.0);
@@ -77,7 +78,8 @@ int main(int argc, const char *argv[]) {
             }
             renderer.render(p, nullptr, rgb8.data());
             rt_counters c = renderer.counters();
-            unsigned long long rays = c.rays_primary + c.rays_shadow + c.rays_secondary;
+            unsigned long long rays_total = c.rays_primary + c.rays_shadow + c.rays_secondary, rays = rays_total - rays_before;
+            rays_before = rays_total;  // the counters accumulate over frames
             std::cout << "frame " << f << ": trace kernel " << c.last_trace_ms << " ms, " << rays << " rays, " << rays / (c.last_trace_ms * 1e3)
                       << " Mrays/s; LBVH build " << c.last_build_ms << " ms (once)" << std::endl;
             std::string path = out;
