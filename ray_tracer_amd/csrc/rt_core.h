@@ -1072,8 +1072,53 @@ RT_HD v3 shade_end(const DevScene &S, const ShadeCtx &sc, Work &wk) {
 //   bool next(v3 &o, v3 &d);  void done(v3 radiance);  rt_hit_record *first_hit();
 struct Pending { v3 o, d; float w; int32_t depth; };
 
+// The same for scenes without reflective or refractive materials, where every primary ray ends in
+// direct lighting: primary query, then one shadow query per light, as plain nested loops.  The lanes
+// of a wave stay in step (they have the same number of taps and lights), so the light index is a
+// wave-uniform value and neither a ray stage nor a pending stack has to be carried.  A lane without
+// a hit sends NaN shadow rays, which miss everything at no cost.
+template <int F, bool COUNT, class Stack, class Source>
+RT_HD void trace_loop_direct(const DevScene &S, int accel, Stack &stk, Work &wk, Source &src) {
+    v3 o, d;
+    bool live = src.next(o, d);
+    while (wave_ballot(live) != 0) {
+        Closest c;
+        find_closest<F, COUNT>(S, o, d, accel, -1, INFINITY, -INFINITY, c, stk, wk);
+        if (live) wk.rays_primary++;
+        bool hit = live & (c.object >= 0);
+        Surf s;
+        if (hit) resolve<F, COUNT>(S, c, o, d, s, wk);
+        rt_hit_record *fh = src.first_hit();
+        if (fh && live) fill_hit(*fh, c, s);
+        ShadeCtx sc;
+        sc.point = V3(NAN, NAN, NAN);
+        if (hit) shade_begin<F, COUNT>(S, s, d, sc, wk);
+        const int32_t n_lights = S.n_lights;
+        for (int32_t l = 0; l < n_lights; l++) {
+            // shadow ray (main.cpp:650-656): from point + EPS * L towards light l
+            v3 lp = ld3(S.light_pos + 3 * l);
+            v3 L = normalize(lp - sc.point);
+            float light_r = distance(sc.point, lp);
+            Closest cs;
+            find_closest<F, COUNT>(S, sc.point + L * kEps, L, accel, l, light_r * 1.001f + 1e-3f, light_r, cs, stk, wk);
+            if (hit) {
+                wk.rays_shadow++;
+                if (!(cs.distance < light_r)) shade_light<COUNT>(S, sc, l, L, light_r, wk);
+            }
+        }
+        v3 radiance = V3(0, 0, 0);
+        if (hit) radiance = radiance + shade_end<F, COUNT>(S, sc, wk) * 1.0f;
+        if (live) src.done(radiance);
+        live = live && src.next(o, d);
+    }
+}
+
 template <int F, bool COUNT, class Stack, class Source>
 RT_HD void trace_loop(const DevScene &S, int max_depth, int accel, Stack &stk, Work &wk, Source &src) {
+    if (!(F & F_SECONDARY)) {
+        trace_loop_direct<F, COUNT>(S, accel, stk, wk, src);
+        return;
+    }
     Pending pend[(F & F_SECONDARY) ? RT_MAX_DEPTH + 1 : 1];
     int np = 0;
     v3 o, d;
