@@ -176,6 +176,15 @@ RT_HD float clamp01(float x) { float m = (x < 0.0f) ? 0.0f : x; return (1.0f < m
 // matching variant and needs no per-lane min / max to order the slab distances.  Variant o of node i
 // of a mesh with n nodes is nodes[node_offset + o * n + i].
 constexpr int kOctants = 8;
+// What can shadow light l, summarised for a whole wave of shadow rays.  A shadow ray ends at the
+// light, so seen from the light it lies on a line through the light; it can only meet a mesh if that
+// line enters the cone from the light around the mesh's bounding sphere.  cone[k] = {axis (negated:
+// shadow rays run TOWARDS the light), cos of the half angle} for mesh k; cos = 2 marks an unused
+// slot.  Light l is `cullable` when nothing but at most kCullMeshes meshes can shadow it (every plane
+// has the light on its front side, there are no quadrics): then a wave whose rays are all outside
+// all cones needs no shadow query at all.
+constexpr int kCullMeshes = 4;
+struct alignas(64) LightCull { f4 cone[kCullMeshes]; };
 struct BvhNode {
     float lo0[3], hi0[3];
     float lo1[3], hi1[3];
@@ -253,6 +262,9 @@ struct DevScene {
     const float *tri_uv;       // [n][6]
     const int32_t *tri_material, *tri_frag, *tri_sub;
     const f4 *gate_tri;        // 3 x f4 per Box triangle, 12 per mesh
+    const LightCull *light_cull;  // per light
+    uint32_t cullable_lights;     // bit l: light_cull[l] decides alone whether a shadow query is needed (l < 32)
+    int32_t pad1;
     const BvhNode *nodes;
     const rt_material *materials;
     const DevTexture *textures;
@@ -1100,7 +1112,18 @@ RT_HD void trace_loop_direct(const DevScene &S, int accel, Stack &stk, Work &wk,
             v3 L = normalize(lp - sc.point);
             float light_r = distance(sc.point, lp);
             Closest cs;
-            find_closest<F, COUNT>(S, sc.point + L * kEps, L, accel, l, light_r * 1.001f + 1e-3f, light_r, cs, stk, wk);
+            cs.distance = INFINITY;
+            bool query = true;
+            if (l < 32 && ((S.cullable_lights >> l) & 1u)) {
+                u32x16 lc = load_u32x16(S.light_cull + l);
+                pin_scalar(lc);
+                float c0 = dot(L, V3(u2f(lc[0]), u2f(lc[1]), u2f(lc[2]))), c1 = dot(L, V3(u2f(lc[4]), u2f(lc[5]), u2f(lc[6])));
+                float c2 = dot(L, V3(u2f(lc[8]), u2f(lc[9]), u2f(lc[10]))), c3 = dot(L, V3(u2f(lc[12]), u2f(lc[13]), u2f(lc[14])));
+                bool in0 = !(c0 < u2f(lc[3])), in1 = !(c1 < u2f(lc[7])), in2 = !(c2 < u2f(lc[11])), in3 = !(c3 < u2f(lc[15]));
+                bool near_mesh = hit & (in0 | in1 | in2 | in3);
+                query = wave_ballot(near_mesh) != 0;  // nothing can lie between these points and the light
+            }
+            if (query) find_closest<F, COUNT>(S, sc.point + L * kEps, L, accel, l, light_r * 1.001f + 1e-3f, light_r, cs, stk, wk);
             if (hit) {
                 wk.rays_shadow++;
                 if (!(cs.distance < light_r)) shade_light<COUNT>(S, sc, l, L, light_r, wk);

@@ -429,6 +429,10 @@ extern "C" int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *sc) {
     ctx->n_nodes = node_total;
     f4 *d_gate;
     if ((rc = dev_alloc(ctx, &d_gate, gate.size(), gate.data()))) return rc;
+    std::vector<LightCull> cull;
+    uint32_t cullable = make_light_cull(sc, ctx->meshes, axis_planes, gen_planes, cull);
+    LightCull *d_cull;
+    if ((rc = dev_alloc(ctx, &d_cull, cull.size(), cull.data()))) return rc;
     if ((rc = dev_alloc(ctx, &ctx->d_nodes, (size_t)node_total, (const void *)nullptr))) return rc;
     if ((rc = dev_alloc(ctx, &ctx->d_meshes, ctx->meshes.size(), ctx->meshes.data()))) return rc;
 
@@ -451,7 +455,7 @@ extern "C" int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *sc) {
     S.objects = d_objects; S.spheres = d_spheres; S.planes = d_planes; S.cones = d_cones; S.meshes = ctx->d_meshes;
     S.tri_test = ctx->d_tri_test; S.tri_key = ctx->d_tri_key; S.tri_orig = ctx->d_tri_orig;
     S.tri_nrm = d_nrm; S.tri_uv = d_uv; S.tri_material = d_tmat; S.tri_frag = ctx->d_tri_frag; S.tri_sub = ctx->d_tri_sub;
-    S.gate_tri = d_gate; S.nodes = ctx->d_nodes; S.materials = d_materials; S.textures = d_tex;
+    S.gate_tri = d_gate; S.light_cull = d_cull; S.cullable_lights = cullable; S.pad1 = 0; S.nodes = ctx->d_nodes; S.materials = d_materials; S.textures = d_tex;
     S.light_pos = d_lp; S.light_color = d_lc;
     for (int a = 0; a < 3; a++) S.ambient[a] = sc->ambient[a];
     RT_HIP(hipStreamSynchronize(ctx->stream));  // the caller's arrays may go away after return
@@ -523,6 +527,9 @@ extern "C" int rt_scene_update(rt_ctx *ctx, const rt_scene_desc *sc) {
     }
     ctx->meshes = meshes;
     if ((rc = dev_update(ctx, S.gate_tri, gate.data(), gate.size()))) return rc;
+    std::vector<LightCull> cull;
+    S.cullable_lights = make_light_cull(sc, ctx->meshes, axis_planes, gen_planes, cull);
+    if ((rc = dev_update(ctx, S.light_cull, cull.data(), cull.size()))) return rc;
     if ((rc = dev_update(ctx, S.meshes, ctx->meshes.data(), ctx->meshes.size()))) return rc;
     for (int a = 0; a < 3; a++) S.ambient[a] = sc->ambient[a];
     RT_HIP(hipStreamSynchronize(ctx->stream));  // the caller's arrays may go away after return

@@ -188,6 +188,54 @@ inline int prepare_meshes(const rt_scene_desc *sc, std::vector<DevMesh> &meshes,
     return node_total;
 }
 
+// The shadow-query summaries per light (LightCull) and the mask of lights they are valid for.
+// Needs the world boxes prepare_meshes computed and the plane records' cannot_shadow bits.
+inline uint32_t make_light_cull(const rt_scene_desc *sc, const std::vector<DevMesh> &meshes, const std::vector<AxisPlaneRec> &axis,
+                                const std::vector<PlaneRec> &gen, std::vector<LightCull> &cull) {
+    LightCull none;
+    for (int k = 0; k < kCullMeshes; k++) none.cone[k] = f4{0, 0, 0, 2.0f};
+    cull.assign(std::max(sc->n_lights, 1), none);
+    uint32_t cullable = 0;
+    // objects of other kinds in the object list, and meshes beyond the table's capacity, forbid culling
+    int listed_meshes = 0;
+    for (const DevMesh &m : meshes) if (m.object >= 0) listed_meshes++;
+    bool quadrics = false;
+    for (int i = 0; i < sc->n_objects; i++) quadrics = quadrics || sc->objects[i].kind == RT_OBJ_SPHERE || sc->objects[i].kind == RT_OBJ_CONE;
+    if (quadrics || listed_meshes > kCullMeshes) return 0;
+    for (int l = 0; l < sc->n_lights && l < 32; l++) {
+        bool ok = true;
+        for (const AxisPlaneRec &r : axis) if (r.axis != 0 && !((r.cannot_shadow >> l) & 1u)) ok = false;
+        for (const PlaneRec &r : gen) if (r.object >= 0 && !((r.cannot_shadow >> l) & 1u)) ok = false;
+        int slot = 0;
+        for (size_t i = 0; i < meshes.size() && ok; i++) {
+            const DevMesh &m = meshes[i];
+            if (m.object < 0) continue;
+            f4 &out = cull[l].cone[slot++];
+            out = f4{0, 0, 0, -2.0f};  // unless shown otherwise: always inside the cone
+            double c[3], r2 = 0, v[3], dist2 = 0;
+            bool bounded = true;
+            for (int a = 0; a < 3; a++) {
+                bounded = bounded && std::isfinite(m.world_lo[a]) && std::isfinite(m.world_hi[a]);
+                c[a] = 0.5 * ((double)m.world_lo[a] + m.world_hi[a]);
+                double h = 0.5 * ((double)m.world_hi[a] - m.world_lo[a]);
+                r2 += h * h;
+                v[a] = c[a] - (double)sc->light_pos[3 * l + a];
+                dist2 += v[a] * v[a];
+            }
+            if (!bounded) continue;
+            double dist = std::sqrt(dist2);
+            // shadow rays pass the light only up to rounding and their EPS offset: inflate the sphere well beyond that
+            double R = std::sqrt(r2) * 1.001 + 1e-3 * dist + 1e-3;
+            if (!(dist > R * 1.001) || !std::isfinite(dist)) continue;
+            double cosv = std::sqrt(1.0 - (R / dist) * (R / dist));
+            out.x = (float)(-v[0] / dist); out.y = (float)(-v[1] / dist); out.z = (float)(-v[2] / dist);
+            out.w = (float)(cosv * (1.0 - 1e-5) - 1e-5);  // covers the float rounding of the axis, the direction and the dot product
+        }
+        if (ok) cullable |= 1u << l;
+    }
+    return cullable;
+}
+
 // the plane records find_closest walks: planes that occur in the object list, split into
 // axis-aligned and general ones, each array padded with inert records to its group size
 inline void make_plane_recs(const rt_scene_desc *sc, const std::vector<int32_t> &plane_obj, std::vector<AxisPlaneRec> &axis,

@@ -39,6 +39,7 @@ struct Twin {
     std::vector<uint32_t> tri_key;
     std::vector<int32_t> tri_orig, tri_material, tri_frag, tri_sub;
     std::vector<int32_t> plane_obj, sphere_obj, cone_obj, mesh_obj;
+    std::vector<LightCull> light_cull;
     std::vector<AxisPlaneRec> axis_planes;
     std::vector<PlaneRec> gen_planes;
     std::vector<float> tri_pos, tri_nrm, tri_uv, light_pos, light_color;
@@ -118,6 +119,8 @@ void *twin_create(const rt_scene_desc *sc, char *errbuf, int errcap) {
     S.meshes = t->meshes.data(); S.tri_test = t->tri_test.data(); S.tri_key = t->tri_key.data(); S.tri_orig = t->tri_orig.data();
     S.tri_nrm = t->tri_nrm.data(); S.tri_uv = t->tri_uv.data(); S.tri_material = t->tri_material.data();
     S.tri_frag = t->tri_frag.data(); S.tri_sub = t->tri_sub.data(); S.gate_tri = t->gate.data(); S.nodes = t->nodes.data();
+    S.cullable_lights = make_light_cull(sc, t->meshes, t->axis_planes, t->gen_planes, t->light_cull);
+    S.light_cull = t->light_cull.data(); S.pad1 = 0;
     S.materials = t->materials.data(); S.textures = t->textures.data();
     S.light_pos = t->light_pos.data(); S.light_color = t->light_color.data();
     for (int a = 0; a < 3; a++) S.ambient[a] = sc->ambient[a];
