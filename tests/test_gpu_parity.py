@@ -272,3 +272,49 @@ def test_scene_update_equals_fresh_upload():
     with pytest.raises(rt.RtError, match="before rt_scene_upload"):
         empty.update(_posed_room(0.0, 16))
     empty.close()
+
+
+def _cull_scene(kind):
+    """Scenes around the shadow-query cull: it may only skip queries that cannot find an occluder."""
+    hs = rt.HostScene()
+    red = rt.Material(ambient=(0.01, 0.02, 0.02), diffuse=(1.0, 0.2, 0.2), specular=0.5, shininess=10.0)
+    teapot = os.path.join(rt.ASSETS, "teapot.obj")
+    n_meshes = 5 if kind == "five_meshes" else 2 if kind == "two_meshes" else 1
+    for k in range(n_meshes):
+        M = rt.scale((0.5, 0.5, 0.5), rt.translate((-6 + 3 * k, 0, 9 + k))) if n_meshes > 1 else rt.translate((0, 1, 10))
+        hs.add_mesh_obj(teapot, M, red, boxed=(k % 2 == 0), flip_normals=True)
+    hs.add_plane((0, -3, 0), (0, 1, 0), rt.Material())
+    hs.add_plane((0, 1, 30), (0, 0, -1), rt.Material())
+    hs.add_plane((-15, 1, 0), (1, 0, 0), rt.Material())
+    if kind == "light_in_sphere":
+        hs.add_light((0.5, 3.5, 10.5), 0.3)     # inside the teapot's bounding sphere: no cone
+    elif kind == "light_behind_plane":
+        hs.add_plane((0, 12, 0), (0, 1, 0), rt.Material())  # a shelf above the teapot, its front side up ...
+        hs.add_light((3, 10, 8), 0.4)                       # ... and a light below it: the shelf can shadow this light
+    else:
+        hs.add_light((10, 16, -7), 0.5)
+    hs.add_light((2, 7, 1), 0.2)
+    return hs
+
+
+@pytest.mark.parametrize("kind", ["room", "light_in_sphere", "light_behind_plane", "two_meshes", "five_meshes"])
+def test_shadow_query_cull_changes_nothing(kind):
+    """The frame kernel of direct-lighting scenes (nested loops, wave-wide skipping of shadow queries) against
+    rt_trace_rays on the same camera rays (general ray loop, no such skipping): identical radiance."""
+    w, h, m = 96, 64, 2
+    ctx = rt.Context(0)
+    ctx.upload(_cull_scene(kind))
+    frame, _ = ctx.render(w, h, mode=rt.MODE_GRID, grid_m=m)
+    o, d, _wts = O.camera_rays(w, h, mode=rt.MODE_GRID, grid_m=m)
+    _, rad = ctx.trace_rays(o, d, want_hits=False)
+    lbvh_brute, _ = ctx.render(w, h, mode=rt.MODE_GRID, grid_m=m, accel=rt.ACCEL_BRUTE)
+    ctx.close()
+    rad = rad.reshape(h * w, m * m, 3)
+    acc = np.zeros((h * w, 3), np.float32)
+    for k in range(m * m):
+        acc = acc + rad[:, k] * np.float32(1.0)
+    want = (acc / np.float32(m * m)).reshape(h, w, 3)
+    assert np.array_equal(frame, want, equal_nan=True)
+    assert np.array_equal(frame, lbvh_brute, equal_nan=True)
+    lit = frame.reshape(-1, 3).sum(axis=1)
+    assert (lit > 0).mean() > 0.5 and np.unique(np.round(lit, 3)).size > 50  # a real picture with shading and shadows
