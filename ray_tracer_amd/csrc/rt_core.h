@@ -1071,10 +1071,12 @@ RT_HD v3 shade_end(const DevScene &S, const ShadeCtx &sc, Work &wk) {
 
 // ---------------------------------------------------------------- trace loop
 
-// trace_ray (main.cpp:716-761) for a stream of primary rays, as ONE loop around ONE closest-hit
-// query: radiance rays and shadow rays of different lanes share the query, so a wave stays busy
-// while its lanes are at different stages.  The reference's result is linear in the radiance of
-// the child rays, so each pending ray carries the product of the blend factors on its path:
+// trace_ray (main.cpp:716-761) for a stream of primary rays, without recursion: an outer loop takes
+// one radiance ray (primary, reflection or refraction) per lane and iteration; after its closest-hit
+// query all lanes run PhongModel's light loop in step (shade_lights: one shadow query per light, the
+// light index wave-uniform); then the lane continues with a child ray, a pending ray or its next
+// primary ray.  The reference's result is linear in the radiance of the child rays, so each pending
+// ray carries the product of the blend factors on its path:
 //   local shading      weight * (1 - refl) * (ratio if refractive else 1)
 //   refraction child   weight * (1 - refl) * (1 - ratio)
 //   reflection child   weight * refl
@@ -1083,6 +1085,9 @@ RT_HD v3 shade_end(const DevScene &S, const ShadeCtx &sc, Work &wk) {
 // Source supplies primary rays and receives their radiance:
 //   bool next(v3 &o, v3 &d);  void done(v3 radiance);  rt_hit_record *first_hit();
 struct Pending { v3 o, d; float w; int32_t depth; };
+
+template <int F, bool COUNT, class Stack>
+RT_HD void shade_lights(const DevScene &S, ShadeCtx &sc, bool hit, int accel, Stack &stk, Work &wk);
 
 // The same for scenes without reflective or refractive materials, where every primary ray ends in
 // direct lighting: primary query, then one shadow query per light, as plain nested loops.  The lanes
@@ -1105,34 +1110,43 @@ RT_HD void trace_loop_direct(const DevScene &S, int accel, Stack &stk, Work &wk,
         ShadeCtx sc;
         sc.point = V3(NAN, NAN, NAN);
         if (hit) shade_begin<F, COUNT>(S, s, d, sc, wk);
-        const int32_t n_lights = S.n_lights;
-        for (int32_t l = 0; l < n_lights; l++) {
-            // shadow ray (main.cpp:650-656): from point + EPS * L towards light l
-            v3 lp = ld3(S.light_pos + 3 * l);
-            v3 L = normalize(lp - sc.point);
-            float light_r = distance(sc.point, lp);
-            Closest cs;
-            cs.distance = INFINITY;
-            bool query = true;
-            if (l < 32 && ((S.cullable_lights >> l) & 1u)) {
-                u32x16 lc = load_u32x16(S.light_cull + l);
-                pin_scalar(lc);
-                float c0 = dot(L, V3(u2f(lc[0]), u2f(lc[1]), u2f(lc[2]))), c1 = dot(L, V3(u2f(lc[4]), u2f(lc[5]), u2f(lc[6])));
-                float c2 = dot(L, V3(u2f(lc[8]), u2f(lc[9]), u2f(lc[10]))), c3 = dot(L, V3(u2f(lc[12]), u2f(lc[13]), u2f(lc[14])));
-                bool in0 = !(c0 < u2f(lc[3])), in1 = !(c1 < u2f(lc[7])), in2 = !(c2 < u2f(lc[11])), in3 = !(c3 < u2f(lc[15]));
-                bool near_mesh = hit & (in0 | in1 | in2 | in3);
-                query = wave_ballot(near_mesh) != 0;  // nothing can lie between these points and the light
-            }
-            if (query) find_closest<F, COUNT>(S, sc.point + L * kEps, L, accel, l, light_r * 1.001f + 1e-3f, light_r, cs, stk, wk);
-            if (hit) {
-                wk.rays_shadow++;
-                if (!(cs.distance < light_r)) shade_light<COUNT>(S, sc, l, L, light_r, wk);
-            }
-        }
+        shade_lights<F, COUNT>(S, sc, hit, accel, stk, wk);
         v3 radiance = V3(0, 0, 0);
         if (hit) radiance = radiance + shade_end<F, COUNT>(S, sc, wk) * 1.0f;
         if (live) src.done(radiance);
         live = live && src.next(o, d);
+    }
+}
+
+// One shadow query per light for the hit in `sc` (main.cpp:650-685), for all lanes of the wave in
+// step: the light index is wave-uniform.  A lane without a hit (`hit` false, sc.point NaN) sends NaN
+// rays, which miss everything at no cost.
+template <int F, bool COUNT, class Stack>
+RT_HD void shade_lights(const DevScene &S, ShadeCtx &sc, bool hit, int accel, Stack &stk, Work &wk) {
+    const int32_t n_lights = S.n_lights;
+    for (int32_t l = 0; l < n_lights; l++) {
+        // shadow ray (main.cpp:650-656): from point + EPS * L towards light l
+        v3 lp = ld3(S.light_pos + 3 * l);
+        v3 L = normalize(lp - sc.point);
+        float light_r = distance(sc.point, lp);
+        Closest cs;
+        cs.distance = INFINITY;
+        bool query = true;
+        if (l < 32 && ((S.cullable_lights >> l) & 1u)) {
+            u32x16 lc = load_u32x16(S.light_cull + l);
+            pin_scalar(lc);
+            float c0 = dot(L, V3(u2f(lc[0]), u2f(lc[1]), u2f(lc[2]))), c1 = dot(L, V3(u2f(lc[4]), u2f(lc[5]), u2f(lc[6])));
+            float c2 = dot(L, V3(u2f(lc[8]), u2f(lc[9]), u2f(lc[10]))), c3 = dot(L, V3(u2f(lc[12]), u2f(lc[13]), u2f(lc[14])));
+            bool in0 = !(c0 < u2f(lc[3])), in1 = !(c1 < u2f(lc[7])), in2 = !(c2 < u2f(lc[11])), in3 = !(c3 < u2f(lc[15]));
+            bool near_mesh = hit & (in0 | in1 | in2 | in3);
+            query = wave_ballot(near_mesh) != 0;  // nothing can lie between these points and the light
+        }
+        // |L| = 1, so the local ray parameter equals the world distance up to rounding: clip there
+        if (query) find_closest<F, COUNT>(S, sc.point + L * kEps, L, accel, l, light_r * 1.001f + 1e-3f, light_r, cs, stk, wk);
+        if (hit) {
+            wk.rays_shadow++;
+            if (!(cs.distance < light_r)) shade_light<COUNT>(S, sc, l, L, light_r, wk);
+        }
     }
 }
 
@@ -1142,7 +1156,7 @@ RT_HD void trace_loop(const DevScene &S, int max_depth, int accel, Stack &stk, W
         trace_loop_direct<F, COUNT>(S, accel, stk, wk, src);
         return;
     }
-    Pending pend[(F & F_SECONDARY) ? RT_MAX_DEPTH + 1 : 1];
+    Pending pend[RT_MAX_DEPTH + 1];
     int np = 0;
     v3 o, d;
     if (!src.next(o, d)) return;
@@ -1150,51 +1164,27 @@ RT_HD void trace_loop(const DevScene &S, int max_depth, int accel, Stack &stk, W
     float weight = 1.0f;
     int depth = 0;
     bool primary = true;
-    int light = -1;  // -1: the ray in flight is a radiance ray; >= 0: shadow ray towards that light
-    float clip = INFINITY, occl = -INFINITY, light_r = 0;
-    ShadeCtx sc;
     for (;;) {
+        // one radiance ray (primary, reflection or refraction) of every lane
         Closest c;
-        find_closest<F, COUNT>(S, o, d, accel, light, clip, occl, c, stk, wk);
-        bool shade_done = false, ray_done = false;
-        if (light < 0) {
-            if (primary) wk.rays_primary++; else wk.rays_secondary++;
-            Surf s;
-            if (c.object >= 0) resolve<F, COUNT>(S, c, o, d, s, wk);
-            if (primary) {
-                rt_hit_record *fh = src.first_hit();
-                if (fh) fill_hit(*fh, c, s);
-            }
-            primary = false;
-            if (c.object >= 0) {
-                shade_begin<F, COUNT>(S, s, d, sc, wk);
-                light = 0;
-                shade_done = S.n_lights == 0;
-            } else {
-                ray_done = true;
-            }
-        } else {
-            wk.rays_shadow++;
-            if (!(c.distance < light_r)) shade_light<COUNT>(S, sc, light, d, light_r, wk);
-            light++;
-            shade_done = light >= S.n_lights;
+        find_closest<F, COUNT>(S, o, d, accel, -1, INFINITY, -INFINITY, c, stk, wk);
+        if (primary) wk.rays_primary++; else wk.rays_secondary++;
+        bool hit = c.object >= 0;
+        Surf s;
+        if (hit) resolve<F, COUNT>(S, c, o, d, s, wk);
+        if (primary) {
+            rt_hit_record *fh = src.first_hit();
+            if (fh) fill_hit(*fh, c, s);
         }
-        if (!ray_done && !shade_done) {
-            // next shadow ray (main.cpp:650-656): from point + EPS * L towards light `light`
-            v3 lp = ld3(S.light_pos + 3 * light);
-            v3 L = normalize(lp - sc.point);
-            o = sc.point + L * kEps;
-            d = L;
-            light_r = distance(sc.point, lp);
-            occl = light_r;
-            clip = light_r * 1.001f + 1e-3f;  // |L| = 1, so the local ray parameter equals the world distance up to rounding
-            continue;
-        }
-        if (shade_done) {
-            light = -1; clip = INFINITY; occl = -INFINITY;
+        primary = false;
+        ShadeCtx sc;
+        sc.point = V3(NAN, NAN, NAN);
+        if (hit) shade_begin<F, COUNT>(S, s, d, sc, wk);
+        shade_lights<F, COUNT>(S, sc, hit, accel, stk, wk);
+        if (hit) {
             const rt_material &m = S.materials[sc.material];
             v3 local = shade_end<F, COUNT>(S, sc, wk);
-            float refl = (F & F_SECONDARY) ? m.reflectiveness : 0.0f, refr = (F & F_SECONDARY) ? m.refractiveness : 0.0f;
+            float refl = m.reflectiveness, refr = m.refractiveness;
             float ratio = m.refractive_ratio;
             float w_after_refl = refl > 0 ? weight * (1 - refl) : weight;
             float w_local = refr > 0 ? w_after_refl * ratio : w_after_refl;
@@ -1214,14 +1204,14 @@ RT_HD void trace_loop(const DevScene &S, int max_depth, int accel, Stack &stk, W
                 if (have_next) {
                     if (np <= RT_MAX_DEPTH) { pend[np].o = ro2; pend[np].d = rdir; pend[np].w = rw; pend[np].depth = cd; np++; }
                 } else {
-                    o = ro2; d = rdir; weight = rw; depth = cd; have_next = true;
+                    o = ro2; d = rdir; weight = rw; depth = cd;
                     continue;
                 }
             }
             if (have_next) { weight = w_after_refl * (1.f - ratio); depth = cd; continue; }
         }
         // this ray's subtree is finished: resume a pending ray, else hand the radiance over
-        if ((F & F_SECONDARY) && np > 0) {
+        if (np > 0) {
             np--;
             o = pend[np].o; d = pend[np].d; weight = pend[np].w; depth = pend[np].depth;
             continue;
