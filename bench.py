@@ -5,7 +5,9 @@
 
 One step = one whole frame: every rank renders its interleaved 16x16 tiles with the HIP trace
 kernel, the tile-major shards are all-gathered over RCCL (N > 1) and de-interleaved into the
-row-major frame on every rank.  Scene, LBVH and output buffers are resident in HBM before the
+row-major frame on every rank.  The frame is what the reference produces: 8-bit RGB after tone mapping
+and quantisation (main.cpp:1184-1189, Image.cpp:35-39); --float-frame also delivers the linear float
+frame (4x the bytes through the kernel's stores, the all-gather and the de-interleave).  Scene, LBVH and output buffers are resident in HBM before the
 timed region.  Rank 0 prints one JSON line: metric = Mrays/s where one ray is one closest-hit
 query (primary, shadow, reflection, refraction alike), plus the roofline of the trace kernel and
 a CPU baseline (the oracle restatement of the reference's brute-force loop, timed on a sample).
@@ -70,6 +72,7 @@ def main():
     ap.add_argument("--workload", default="teapot_4k_16spp", choices=sorted(WORKLOADS))
     ap.add_argument("--accel", default="lbvh", choices=["lbvh", "brute"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--float-frame", action="store_true", help="also produce the linear float frame")
     args = ap.parse_args()
 
     import torch
@@ -103,23 +106,28 @@ def main():
     per_rank, total_tiles = ctx.shard_tiles(p)
     shard_elems = per_rank * rt.TILE * rt.TILE * 3
     dev = torch.device("cuda", local_rank)
-    shard = torch.zeros(shard_elems, dtype=torch.float32, device=dev)
+    ff = args.float_frame
+    shard = torch.zeros(shard_elems, dtype=torch.float32, device=dev) if ff else None
     shard8 = torch.zeros(shard_elems, dtype=torch.uint8, device=dev)
-    gathered = torch.zeros(world * shard_elems, dtype=torch.float32, device=dev) if world > 1 else shard
+    gathered = (torch.zeros(world * shard_elems, dtype=torch.float32, device=dev) if world > 1 else shard) if ff else None
     gathered8 = torch.zeros(world * shard_elems, dtype=torch.uint8, device=dev) if world > 1 else shard8
-    frame = torch.zeros(height * width * 3, dtype=torch.float32, device=dev)
+    frame = torch.zeros(height * width * 3, dtype=torch.float32, device=dev) if ff else None
     frame8 = torch.zeros(height * width * 3, dtype=torch.uint8, device=dev)
+
+    def ptr(t):
+        return t.data_ptr() if t is not None else None
 
     def step(events=None):
         if events is not None:
             events[0].record(stream)
-        ctx.render_shard_device(p, shard.data_ptr(), shard8.data_ptr())
+        ctx.render_shard_device(p, ptr(shard), ptr(shard8))
         if events is not None:
             events[1].record(stream)
         if world > 1:
-            dist.all_gather_into_tensor(gathered, shard)
+            if ff:
+                dist.all_gather_into_tensor(gathered, shard)
             dist.all_gather_into_tensor(gathered8, shard8)
-        ctx.untile_device(p, gathered.data_ptr(), frame.data_ptr(), gathered8.data_ptr(), frame8.data_ptr())
+        ctx.untile_device(p, ptr(gathered), ptr(frame), ptr(gathered8), ptr(frame8))
 
     def barrier():
         if world > 1:
@@ -153,7 +161,7 @@ def main():
     ctx.reset_counters()
     pc = ctx.params(width, height, mode=mode, grid_m=grid_m, max_depth=max_depth, accel=accel,
                     rank=rank, world_size=world, count_work=True)
-    ctx.render_shard_device(pc, shard.data_ptr(), shard8.data_ptr())
+    ctx.render_shard_device(pc, ptr(shard), ptr(shard8))
     torch.cuda.synchronize()
     cw = ctx.counters()
     flops_local = (cw.tri_tests * FLOPS["tri_tests"] + cw.box_tests * FLOPS["box_tests"] +
@@ -179,6 +187,7 @@ def main():
             "config": {"workload": args.workload, "preset": preset, "width": width, "height": height,
                        "samples_per_pixel": 1 if mode == 0 else 9 if mode == 1 else grid_m * grid_m,
                        "max_depth": max_depth, "accel": args.accel, "tiles": total_tiles,
+                       "frame": "rgb8+f32" if ff else "rgb8",
                        "parallelism": f"tiles{world}", "rays_per_frame": rays_total / args.steps,
                        "bvh_height": c.bvh_max_depth, "lbvh_build_ms": c.last_build_ms},
             "roofline": {"bound": "valu", "achieved": achieved_tflops, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",

@@ -240,7 +240,10 @@ struct DevTexture {
     int32_t kind;
     uint32_t w, h;
     uint32_t pad;
-    const uint8_t *maps[4];  // base colour, normal, occlusion, roughness
+    // image textures: one 16-byte record per texel holding the RGBA8 texels of all four maps
+    // (x base colour, y normal, z occlusion, w roughness), so that a shaded hit costs one fetch
+    const u4 *texels;
+    const void *pad2[3];
 };
 
 struct DevScene {
@@ -268,6 +271,7 @@ struct DevScene {
     const BvhNode *nodes;
     const rt_material *materials;
     const DevTexture *textures;
+    const float *srgb_lut;     // [256] pow(b / 255, 2.2): the base-colour decoding of Textures.cpp:41-43 per byte value
     const float *light_pos, *light_color;
     float ambient[3];
 };
@@ -285,46 +289,36 @@ RT_HD void work_zero(Work &w) {
 // ---------------------------------------------------------------- textures
 
 // ImageTexture::getRGBAat, Textures.cpp:27-35.  `int % unsigned` is unsigned arithmetic.
+// ImageTexture::getRGBAat (Textures.cpp:26-39) for all four maps at once: the texel record at uv
 template <bool COUNT>
-RT_HD f4 tex_rgba(const DevTexture &t, int map, v2 uv, Work &wk) {
+RT_HD u4 tex_texel(const DevTexture &t, v2 uv, Work &wk) {
     if (COUNT) wk.tex++;
     float fx = 2 * uv.x * (float)t.w;
     float fy = 2 * uv.y * (float)t.h;
     int xi = (int)roundf(fx), yi = (int)roundf(fy);
     uint32_t x = (uint32_t)xi % t.w;
     uint32_t y = (uint32_t)yi % t.h;
-    uint32_t index = (y * t.w + x) * 4u;
-    const uint8_t *p = t.maps[map] + index;
-#if defined(__HIP_DEVICE_COMPILE__)
-    uint32_t px = *reinterpret_cast<const uint32_t *>(p);
+    return t.texels[y * t.w + x];
+}
+RT_HD f4 unpack_rgba8(uint32_t px) {
     f4 r;
     r.x = (float)(px & 255u) / 255.f; r.y = (float)((px >> 8) & 255u) / 255.f;
     r.z = (float)((px >> 16) & 255u) / 255.f; r.w = (float)(px >> 24) / 255.f;
     return r;
-#else
-    f4 r;
-    r.x = (float)p[0] / 255.f; r.y = (float)p[1] / 255.f; r.z = (float)p[2] / 255.f; r.w = (float)p[3] / 255.f;
-    return r;
-#endif
 }
-// Texture::texture(uv): Textures.cpp:9-24 and 41-43
-template <bool COUNT>
-RT_HD v3 tex_color(const DevTexture &t, v2 uv, Work &wk) {
-    if (t.kind == RT_TEX_CHECKER) {
+RT_HD v3 unpack_rgb8(uint32_t px) { f4 c = unpack_rgba8(px); return V3(c.x, c.y, c.z); }
+// Texture::texture(uv) of the procedural textures: Textures.cpp:9-24
+RT_HD v3 tex_procedural(int kind, v2 uv) {
+    if (kind == RT_TEX_CHECKER) {
         int v = (int)(floorf(16 * uv.x) + floorf(16 * uv.y)) % 2;
         return V3((float)v, (float)v, (float)v);
     }
-    if (t.kind == RT_TEX_RAINBOW) {
-        int v = (int)floorf(18 * (uv.x + uv.y)) % 3;
-        return v == 0 ? V3(1, 0, 0) : v == 1 ? V3(0, 1, 0) : v == 2 ? V3(0, 0, 1) : V3(0, 0, 0);
-    }
-    f4 c = tex_rgba<COUNT>(t, 0, uv, wk);
-    return V3(powf(c.x, 2.2f), powf(c.y, 2.2f), powf(c.z, 2.2f));
+    int v = (int)floorf(18 * (uv.x + uv.y)) % 3;
+    return v == 0 ? V3(1, 0, 0) : v == 1 ? V3(0, 1, 0) : v == 2 ? V3(0, 0, 1) : V3(0, 0, 0);
 }
-template <bool COUNT>
-RT_HD v3 tex_rgb(const DevTexture &t, int map, v2 uv, Work &wk) {
-    f4 c = tex_rgba<COUNT>(t, map, uv, wk);
-    return V3(c.x, c.y, c.z);
+// ImageTexture::texture (Textures.cpp:41-43): pow(channel, 2.2) of the base colour, from the table
+RT_HD v3 tex_base_color(const DevScene &S, uint32_t px) {
+    return V3(S.srgb_lut[px & 255u], S.srgb_lut[(px >> 8) & 255u], S.srgb_lut[(px >> 16) & 255u]);
 }
 RT_HD const DevTexture *image_texture_of(const DevScene &S, const rt_material &m) {
     if (m.texture < 0) return nullptr;
@@ -335,6 +329,8 @@ RT_HD const DevTexture *image_texture_of(const DevScene &S, const rt_material &m
 // ---------------------------------------------------------------- analytic primitives
 
 struct Surf {  // a resolved hit (Hit, main.cpp:45-53)
+    u4 texel;         // the texture record at uv, when the surface function fetched it
+    bool has_texel;
     v3 point, normal;
     v2 uv;
     int32_t material;
@@ -358,8 +354,11 @@ RT_HD void plane_surface(const DevScene &S, const rt_plane &pl, v3 ro, v3 rd, fl
     s.uv.y = dot(b2, s.point);
     s.material = pl.material;
     const DevTexture *it = (F & F_TEXTURE) ? image_texture_of(S, S.materials[pl.material]) : nullptr;
+    s.has_texel = false;
     if (it) {
-        v3 tn = tex_rgb<COUNT>(*it, 1, s.uv, wk);
+        s.texel = tex_texel<COUNT>(*it, s.uv, wk);
+        s.has_texel = true;
+        v3 tn = unpack_rgb8(s.texel.y);
         tn = tn * 2.f - V3(1, 1, 1);
         n = m3_mul(b1, b2, n, tn);
     }
@@ -410,10 +409,13 @@ RT_HD void sphere_surface(const DevScene &S, const rt_sphere &sp, const QuadricH
     s.material = sp.material;
     const DevTexture *it = (F & F_TEXTURE) ? image_texture_of(S, S.materials[sp.material]) : nullptr;
     v3 n;
+    s.has_texel = false;
     if (it) {
         v3 tangent = V3(sinf(s.uv.x), 0, cosf(s.uv.x));
         v3 bitangent = cross(i, tangent);
-        v3 tn = tex_rgb<COUNT>(*it, 1, s.uv, wk);
+        s.texel = tex_texel<COUNT>(*it, s.uv, wk);
+        s.has_texel = true;
+        v3 tn = unpack_rgb8(s.texel.y);
         tn = tn * 2.f - V3(1, 1, 1);
         tn = m3_mul(normalize(tangent), normalize(bitangent), normalize(i), tn);
         n = xform_dir(sp.normal_mat, tn);
@@ -460,6 +462,7 @@ RT_HD bool cone_geom(const rt_cone &cn, v3 ro, v3 rd, QuadricHit &q) {
 }
 template <int F, bool COUNT>
 RT_HD void cone_surface(const DevScene &S, const rt_cone &cn, const QuadricHit &q, Surf &s, Work &wk) {
+    s.has_texel = false;
     v3 n;
     if (q.cap) {
         Surf ps;
@@ -762,6 +765,7 @@ RT_HD bool mesh_geom(const DevScene &S, const MeshHead &h, const DevMesh &m, v3 
     return true;
 }
 RT_HD void mesh_surface(const DevScene &S, const DevMesh &m, v3 ro, v3 rd, float t, int32_t k, Surf &s) {
+    s.has_texel = false;
     v3 d = xform_dir(m.to_local, rd);
     v3 o = xform_point(m.to_local, ro);
     v3 p, n; int32_t orig;
@@ -1016,7 +1020,7 @@ struct ShadeCtx {
     v3 view;                 // normalize(-d_in)
     v3 color;                // running sum, starts at ambient_light * material.ambient
     v3 dc;                   // diffuse colour (texture(uv) or material.diffuse), x5 for image textures
-    v2 uv;
+    uint32_t occlusion_px;   // RGBA8 texel of the occlusion map (image-textured surfaces)
     float shininess;
     int32_t material;
     bool from_outside;
@@ -1025,19 +1029,22 @@ struct ShadeCtx {
 template <int F, bool COUNT>
 RT_HD void shade_begin(const DevScene &S, const Surf &s, v3 d_in, ShadeCtx &sc, Work &wk) {
     const rt_material &m = S.materials[s.material];
-    sc.point = s.point; sc.normal = s.normal; sc.d_in = d_in; sc.uv = s.uv;
+    sc.point = s.point; sc.normal = s.normal; sc.d_in = d_in; sc.occlusion_px = 0;
     sc.view = normalize(-d_in);
     sc.material = s.material; sc.from_outside = s.from_outside;
     sc.color = ld3(S.ambient) * ld3(m.ambient);
     const DevTexture *tex = ((F & F_TEXTURE) && m.texture >= 0) ? &S.textures[m.texture] : nullptr;
     const DevTexture *img = (tex && tex->kind == RT_TEX_IMAGE) ? tex : nullptr;
     sc.dc = ld3(m.diffuse);
-    if (tex) sc.dc = tex_color<COUNT>(*tex, s.uv, wk);
+    if (tex && !img) sc.dc = tex_procedural(tex->kind, s.uv);
     sc.shininess = m.shininess;
     if (img) {
-        sc.dc = sc.dc * 5.f;  // diffuse *= 5 (main.cpp:673) commutes with the NdotL factor
+        u4 texel = s.texel;
+        if (!s.has_texel) texel = tex_texel<COUNT>(*img, s.uv, wk);  // surfaces without a normal-mapped branch (cones, meshes)
+        sc.occlusion_px = texel.z;
+        sc.dc = tex_base_color(S, texel.x) * 5.f;  // diffuse *= 5 (main.cpp:673) commutes with the NdotL factor
         // .5 / pow(roughness, 4) - .5 in double (main.cpp:674): r*r is exact in double, its square rounds once
-        double r2 = (double)tex_rgba<COUNT>(*img, 3, s.uv, wk).x;
+        double r2 = (double)unpack_rgba8(texel.w).x;
         r2 = r2 * r2;
         sc.shininess = (float)(.5 / (r2 * r2) - .5);
     }
@@ -1064,7 +1071,7 @@ RT_HD v3 shade_end(const DevScene &S, const ShadeCtx &sc, Work &wk) {
     const rt_material &m = S.materials[sc.material];
     const DevTexture *img = (F & F_TEXTURE) ? image_texture_of(S, m) : nullptr;
     v3 color = sc.color;
-    if (img) color = color * tex_rgb<COUNT>(*img, 2, sc.uv, wk);
+    if (img) color = color * unpack_rgb8(sc.occlusion_px);
     else color = color * 4.0f;
     return color * 2.0f;
 }

@@ -389,16 +389,20 @@ extern "C" int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *sc) {
     for (int i = 0; i < sc->n_textures; i++) {
         const rt_texture &t = sc->textures[i];
         tex[i].kind = t.kind; tex[i].w = t.width; tex[i].h = t.height; tex[i].pad = 0;
-        for (int k = 0; k < 4; k++) tex[i].maps[k] = nullptr;
+        tex[i].texels = nullptr;
+        for (int k = 0; k < 3; k++) tex[i].pad2[k] = nullptr;
         if (t.kind == RT_TEX_IMAGE) {
-            const uint8_t *src[4] = {t.base_color, t.normal, t.occlusion, t.roughness};
-            for (int k = 0; k < 4; k++) {
-                uint8_t *d;
-                if ((rc = dev_alloc(ctx, &d, (size_t)t.width * t.height * 4, src[k]))) return rc;
-                tex[i].maps[k] = d;
-            }
+            std::vector<u4> texels;
+            interleave_texture(t, texels);
+            u4 *d;
+            if ((rc = dev_alloc(ctx, &d, texels.size(), texels.data()))) return rc;
+            tex[i].texels = d;
         }
     }
+    std::vector<float> lut;
+    make_srgb_lut(lut);
+    float *d_lut;
+    if ((rc = dev_alloc(ctx, &d_lut, lut.size(), lut.data()))) return rc;
     DevTexture *d_tex;
     if ((rc = dev_alloc(ctx, &d_tex, tex.size(), tex.data()))) return rc;
     std::vector<int32_t> plane_obj, sphere_obj, cone_obj, mesh_obj;
@@ -455,7 +459,7 @@ extern "C" int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *sc) {
     S.objects = d_objects; S.spheres = d_spheres; S.planes = d_planes; S.cones = d_cones; S.meshes = ctx->d_meshes;
     S.tri_test = ctx->d_tri_test; S.tri_key = ctx->d_tri_key; S.tri_orig = ctx->d_tri_orig;
     S.tri_nrm = d_nrm; S.tri_uv = d_uv; S.tri_material = d_tmat; S.tri_frag = ctx->d_tri_frag; S.tri_sub = ctx->d_tri_sub;
-    S.gate_tri = d_gate; S.light_cull = d_cull; S.cullable_lights = cullable; S.pad1 = 0; S.nodes = ctx->d_nodes; S.materials = d_materials; S.textures = d_tex;
+    S.gate_tri = d_gate; S.light_cull = d_cull; S.cullable_lights = cullable; S.pad1 = 0; S.nodes = ctx->d_nodes; S.materials = d_materials; S.textures = d_tex; S.srgb_lut = d_lut;
     S.light_pos = d_lp; S.light_color = d_lc;
     for (int a = 0; a < 3; a++) S.ambient[a] = sc->ambient[a];
     RT_HIP(hipStreamSynchronize(ctx->stream));  // the caller's arrays may go away after return

@@ -236,6 +236,23 @@ inline uint32_t make_light_cull(const rt_scene_desc *sc, const std::vector<DevMe
     return cullable;
 }
 
+// The four RGBA8 maps of an image texture as one 16-byte record per texel.
+inline void interleave_texture(const rt_texture &t, std::vector<u4> &out) {
+    size_t n = (size_t)t.width * t.height;
+    out.resize(n);
+    const uint8_t *src[4] = {t.base_color, t.normal, t.occlusion, t.roughness};
+    for (size_t i = 0; i < n; i++) {
+        uint32_t px[4];
+        for (int k = 0; k < 4; k++) std::memcpy(&px[k], src[k] + 4 * i, 4);
+        out[i] = u4{px[0], px[1], px[2], px[3]};
+    }
+}
+// pow(b / 255, 2.2) per byte value (ImageTexture::texture, Textures.cpp:41-43)
+inline void make_srgb_lut(std::vector<float> &lut) {
+    lut.resize(256);
+    for (int b = 0; b < 256; b++) lut[b] = powf((float)b / 255.f, 2.2f);
+}
+
 // the plane records find_closest walks: planes that occur in the object list, split into
 // axis-aligned and general ones, each array padded with inert records to its group size
 inline void make_plane_recs(const rt_scene_desc *sc, const std::vector<int32_t> &plane_obj, std::vector<AxisPlaneRec> &axis,

@@ -46,7 +46,8 @@ struct Twin {
     std::vector<BvhNode> nodes;
     std::vector<rt_material> materials;
     std::vector<DevTexture> textures;
-    std::vector<std::vector<uint8_t>> maps;
+    std::vector<std::vector<u4>> texels;
+    std::vector<float> srgb_lut;
     int bvh_max_depth = 0;
     Work total{};
 };
@@ -91,15 +92,16 @@ void *twin_create(const rt_scene_desc *sc, char *errbuf, int errcap) {
         const rt_texture &x = sc->textures[i];
         DevTexture &d = t->textures[i];
         d.kind = x.kind; d.w = x.width; d.h = x.height; d.pad = 0;
-        const uint8_t *src[4] = {x.base_color, x.normal, x.occlusion, x.roughness};
-        for (int k = 0; k < 4; k++) {
-            d.maps[k] = nullptr;
-            if (x.kind == RT_TEX_IMAGE) {
-                t->maps.emplace_back(src[k], src[k] + (size_t)x.width * x.height * 4);
-                d.maps[k] = t->maps.back().data();
-            }
+        d.texels = nullptr;
+        for (int k = 0; k < 3; k++) d.pad2[k] = nullptr;
+        if (x.kind == RT_TEX_IMAGE) {
+            t->texels.emplace_back();
+            interleave_texture(x, t->texels.back());
         }
     }
+    for (int i = 0, k = 0; i < sc->n_textures; i++)  // pointers after the outer vector stopped growing
+        if (sc->textures[i].kind == RT_TEX_IMAGE) t->textures[i].texels = t->texels[k++].data();
+    make_srgb_lut(t->srgb_lut);
     int node_total = prepare_meshes(sc, t->meshes, t->build, t->gate);
     t->tri_test.assign(3 * nt, f4{0, 0, 0, 0});
     t->tri_key.assign(nt, 0);
@@ -120,7 +122,8 @@ void *twin_create(const rt_scene_desc *sc, char *errbuf, int errcap) {
     S.tri_nrm = t->tri_nrm.data(); S.tri_uv = t->tri_uv.data(); S.tri_material = t->tri_material.data();
     S.tri_frag = t->tri_frag.data(); S.tri_sub = t->tri_sub.data(); S.gate_tri = t->gate.data(); S.nodes = t->nodes.data();
     S.cullable_lights = make_light_cull(sc, t->meshes, t->axis_planes, t->gen_planes, t->light_cull);
-    S.light_cull = t->light_cull.data(); S.pad1 = 0;
+    S.light_cull = t->light_cull.data();
+    S.srgb_lut = t->srgb_lut.data(); S.pad1 = 0;
     S.materials = t->materials.data(); S.textures = t->textures.data();
     S.light_pos = t->light_pos.data(); S.light_color = t->light_color.data();
     for (int a = 0; a < 3; a++) S.ambient[a] = sc->ambient[a];
