@@ -1259,6 +1259,12 @@ RT_HD Camera make_camera(int w, int h, float fov) {
 }
 RT_HD int taps_of(int mode, int m) { return mode == RT_MODE_REF_1SPP ? 1 : mode == RT_MODE_REF_AA9 ? 9 : m * m; }
 // main.cpp:1241-1266; GRID: corner as in the AA path, taps at ((a+.5)/m*s, -(b+.5)/m*s)
+// weight of tap k in the pixel's sum (main.cpp:1249-1262: 1 2 1 / 2 4 2 / 1 2 1 for the 9-tap mode)
+RT_HD float tap_weight(int mode, int k) {
+    if (mode != RT_MODE_REF_AA9) return 1.0f;
+    int kx = k % 3, ky = k / 3;
+    return (float)((kx == 1 ? 2 : 1) * (ky == 1 ? 2 : 1));
+}
 RT_HD v3 primary_dir(const Camera &c, int mode, int m, int i, int j, int k, float &weight) {
     float s = c.s;
     if (mode == RT_MODE_REF_1SPP) {
@@ -1272,7 +1278,7 @@ RT_HD v3 primary_dir(const Camera &c, int mode, int m, int i, int j, int k, floa
         int kx = k % 3, ky = k / 3;
         float tx = dx + kx * s / 2;
         float ty = dy - ky * s / 2;
-        weight = (float)((kx == 1 ? 2 : 1) * (ky == 1 ? 2 : 1));
+        weight = tap_weight(mode, k);
         return normalize(V3(tx, ty, 1));
     }
     int a = k % m, b = k / m;

@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -27,6 +28,10 @@ namespace {
 
 constexpr int kBlock = 256;
 constexpr int kNumCounters = 10;
+// The counters are kept in kCounterStripes copies, one 128-byte line each; a wave adds to the copy
+// its block and wave number select, and the host adds the copies up.  Hundreds of thousands of waves
+// adding to one address serialise in the L2's atomic unit (measured: 10 % of a 4 ms frame).
+constexpr int kCounterStripes = 4096, kCounterStride = 16;
 
 // ------------------------------------------------------------------ traversal stack in LDS
 
@@ -34,9 +39,9 @@ constexpr int kNumCounters = 10;
 // words each.  All lanes write / read the same words (a broadcast access); the values are made
 // scalar again with readfirstlane.
 // Resident waves per SIMD a render kernel variant is compiled for (register budget 512 / waves).
-// The mesh-only variant fits 96 registers without spilling and gains from the fifth wave; the
-// variants with quadrics, textures or secondary rays would spill there.
-constexpr int render_waves(int features, bool count) { return features == F_MESH && !count ? 5 : 4; }
+// The mesh-only and the quadric-only variants fit 96 registers with few or no spills and gain from
+// the fifth wave; the others would spill heavily there.
+constexpr int render_waves(int features, bool count) { return (features == F_MESH || features == (F_QUADRIC | F_SECONDARY)) && !count ? 5 : 4; }
 constexpr int kWavesPerBlock = kBlock / 64;
 constexpr int kStackWords = 3 * kStackDepth;
 struct WaveStack {
@@ -66,9 +71,10 @@ __device__ __forceinline__ void flush_work(const Work &wk, unsigned long long *c
     unsigned long long vals[kNumCounters] = {wk.rays_primary, wk.rays_shadow, wk.rays_secondary, wk.tri, wk.box,
                                              wk.gate, wk.quadric, wk.plane, wk.shade, wk.tex};
     int n = count ? kNumCounters : 3;
+    unsigned long long *mine = counters + (size_t)((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) % kCounterStripes) * kCounterStride;
     for (int i = 0; i < n; i++) {
         unsigned long long s = wave_sum(vals[i]);
-        if ((threadIdx.x & 63) == 0 && s) atomicAdd(&counters[i], s);
+        if ((threadIdx.x & 63) == 0 && s) atomicAdd(&mine[i], s);
     }
 }
 
@@ -184,6 +190,79 @@ __global__ __launch_bounds__(kBlock, render_waves(F, COUNT)) void k_render(DevSc
     flush_work(wk, counters, COUNT);
 }
 
+// The same frame with the taps of a pixel spread over the four waves of a block: block b renders the
+// 8x8 quadrant b & 3 of local tile b >> 2; in rounds of kRoundTaps taps, wave w traces its quarter of
+// the round's taps for all 64 pixels and leaves each tap's radiance in LDS; wave 0 then adds them to
+// the pixel sums in tap order, exactly as the one-lane-per-pixel kernel does.  With many taps per
+// pixel this bounds the time of the most expensive block to a quarter, which is what limits frames
+// whose cost is concentrated in few pixels.
+constexpr int kRoundTaps = 32;
+struct TapSlice {  // a trace_loop source: taps [k, k_end) of one pixel
+    Camera cam;
+    int mode, grid_m, i, j, k, k_end, base;
+    float wt;
+    float *slots;  // this lane's column of the LDS array [kRoundTaps][3][64]
+    __device__ bool next(v3 &ro, v3 &rd) {
+        if (k >= k_end) return false;
+        ro = V3(0, 0, 0);
+        rd = primary_dir(cam, mode, grid_m, i, j, k, wt);
+        k++;
+        return true;
+    }
+    __device__ void done(v3 r) {
+        float *p = slots + (k - 1 - base) * 3 * 64;
+        p[0] = r.x; p[64] = r.y; p[128] = r.z;
+    }
+    __device__ rt_hit_record *first_hit() { return nullptr; }
+};
+
+template <int F, bool COUNT>
+__global__ __launch_bounds__(kBlock, render_waves(F, COUNT)) void k_render_split(DevScene S, RenderArgs a, float *rgb_tiles,
+                                                                                 uint8_t *rgb8_tiles, unsigned long long *counters) {
+    RT_WAVE_STACK(stk);
+    __shared__ float tap_lds[kRoundTaps * 3 * 64];
+    int local = blockIdx.x >> 2, quad = blockIdx.x & 3;
+    int tile = local * a.world_size + a.rank;
+    int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int px = (quad & 1) * 8 + (lane & 7), py = (quad >> 1) * 8 + (lane >> 3);
+    int i = (tile % a.tiles_x) * RT_TILE_W + px, j = (tile / a.tiles_x) * RT_TILE_H + py;
+    Work wk;
+    work_zero(wk);
+    bool inside = tile < a.tiles_total && i < a.width && j < a.height;
+    const int taps = taps_of(a.mode, a.grid_m);
+    v3 color = V3(0, 0, 0);
+    for (int base = 0; base < taps; base += kRoundTaps) {
+        int n = taps - base < kRoundTaps ? taps - base : kRoundTaps, chunk = (n + 3) >> 2;
+        TapSlice src;
+        src.cam = a.cam; src.mode = a.mode; src.grid_m = a.grid_m; src.i = i; src.j = j; src.base = base; src.wt = 1.0f;
+        src.k = base + wave * chunk;
+        src.k_end = base + ((wave + 1) * chunk < n ? (wave + 1) * chunk : n);
+        src.slots = tap_lds + lane;
+        if (inside && src.k < src.k_end) trace_loop<F, COUNT>(S, a.max_depth, a.accel, stk, wk, src);
+        __syncthreads();
+        if (wave == 0 && inside) {
+            for (int t = 0; t < n; t++) {
+                const float *p = tap_lds + t * 3 * 64 + lane;
+                v3 r = V3(p[0], p[64], p[128]);
+                color = a.mode == RT_MODE_REF_1SPP ? r : color + r * tap_weight(a.mode, base + t);
+            }
+        }
+        __syncthreads();
+    }
+    if (wave == 0) {
+        if (a.mode != RT_MODE_REF_1SPP) color = color / (a.mode == RT_MODE_REF_AA9 ? 16.f : (float)taps);
+        size_t p = ((size_t)local * (RT_TILE_W * RT_TILE_H) + (size_t)py * RT_TILE_W + px) * 3;
+        if (rgb_tiles) { rgb_tiles[p] = color.x; rgb_tiles[p + 1] = color.y; rgb_tiles[p + 2] = color.z; }
+        if (rgb8_tiles) {
+            v3 t = tone_map(color);
+            rgb8_tiles[p] = inside ? quantise(t.x) : 0;
+            rgb8_tiles[p + 1] = inside ? quantise(t.y) : 0;
+            rgb8_tiles[p + 2] = inside ? quantise(t.z) : 0;
+        }
+    }
+    flush_work(wk, counters, COUNT);
+}
+
 // shards[r][local_tile][16][16][3] -> frame[y][x][3]; first_rank/n_ranks select which shards exist
 template <typename T>
 __global__ void k_untile(const T *shards, T *frame, int width, int height, int tiles_x, int tiles_total,
@@ -261,6 +340,8 @@ struct rt_ctx {
     float last_trace_ms = 0, last_build_ms = 0;
     int features = F_ALL;
     int bvh_max_depth = 0;
+    int split_min_taps = 32;  // taps per pixel from which k_render_split is used for scenes with meshes
+    bool split_forced = false;  // RT_SPLIT_MIN_TAPS (tests, tuning) sets the threshold for every scene
 };
 
 #define RT_HIP(call)                                                                             \
@@ -313,9 +394,10 @@ extern "C" int rt_context_create(int device, rt_ctx **out) {
         return RT_ERR_HIP;
     }
     ctx->stream = ctx->own_stream;
+    if (const char *e = std::getenv("RT_SPLIT_MIN_TAPS")) { ctx->split_min_taps = std::atoi(e); ctx->split_forced = true; }
     void *c = nullptr;
-    if (hipMalloc(&c, kNumCounters * sizeof(unsigned long long)) != hipSuccess ||
-        hipMemset(c, 0, kNumCounters * sizeof(unsigned long long)) != hipSuccess) {
+    if (hipMalloc(&c, (size_t)kCounterStripes * kCounterStride * sizeof(unsigned long long)) != hipSuccess ||
+        hipMemset(c, 0, (size_t)kCounterStripes * kCounterStride * sizeof(unsigned long long)) != hipSuccess) {
         delete ctx;
         return RT_ERR_HIP;
     }
@@ -665,15 +747,22 @@ extern "C" int rt_render_shard_device(rt_ctx *ctx, const rt_render_params *p, fl
     int local_tiles = (a.tiles_total - p->rank + p->world_size - 1) / p->world_size;  // tiles t = b*W + rank < total
     if (local_tiles <= 0) return RT_OK;
     RT_HIP(hipEventRecord(ctx->ev0, ctx->stream));
-    // the leanest instantiation that covers the scene's features
-    void (*kernel)(DevScene, RenderArgs, float *, uint8_t *, unsigned long long *) = k_render<F_ALL, false>;
+    // the leanest instantiation that covers the scene's features; with many taps per pixel the
+    // variant that spreads a pixel's taps over the waves of a block
+    typedef void (*render_fn)(DevScene, RenderArgs, float *, uint8_t *, unsigned long long *);
+    // (meshes are what concentrates a frame's cost in few pixels; without them the split only adds its barriers)
+    const bool split = taps_of(p->mode, p->grid_m) >= ctx->split_min_taps && ((ctx->features & F_MESH) || ctx->split_forced);
+    render_fn kernel = split ? k_render_split<F_ALL, false> : k_render<F_ALL, false>;
     int f = ctx->features;
-    if (p->count_work) kernel = k_render<F_ALL, true>;
-    else if ((f & ~F_MESH) == 0) kernel = k_render<F_MESH, false>;
-    else if ((f & ~(F_MESH | F_SECONDARY)) == 0) kernel = k_render<F_MESH | F_SECONDARY, false>;
-    else if ((f & ~(F_QUADRIC | F_SECONDARY)) == 0) kernel = k_render<F_QUADRIC | F_SECONDARY, false>;
-    else if ((f & ~(F_MESH | F_TEXTURE | F_SECONDARY)) == 0) kernel = k_render<F_MESH | F_TEXTURE | F_SECONDARY, false>;
-    hipLaunchKernelGGL(kernel, dim3(local_tiles), dim3(kBlock), 0, ctx->stream, ctx->S, a, d_rgb_tiles, d_rgb8_tiles, ctx->d_counters);
+#define RT_PICK(FEATURES) (split ? (render_fn)k_render_split<FEATURES, false> : (render_fn)k_render<FEATURES, false>)
+    if (p->count_work) kernel = split ? (render_fn)k_render_split<F_ALL, true> : (render_fn)k_render<F_ALL, true>;
+    else if ((f & ~F_MESH) == 0) kernel = RT_PICK(F_MESH);
+    else if ((f & ~(F_MESH | F_SECONDARY)) == 0) kernel = RT_PICK(F_MESH | F_SECONDARY);
+    else if ((f & ~(F_QUADRIC | F_SECONDARY)) == 0) kernel = RT_PICK(F_QUADRIC | F_SECONDARY);
+    else if ((f & ~(F_MESH | F_TEXTURE | F_SECONDARY)) == 0) kernel = RT_PICK(F_MESH | F_TEXTURE | F_SECONDARY);
+#undef RT_PICK
+    hipLaunchKernelGGL(kernel, dim3(split ? 4 * local_tiles : local_tiles), dim3(kBlock), 0, ctx->stream, ctx->S, a, d_rgb_tiles,
+                       d_rgb8_tiles, ctx->d_counters);
     RT_HIP(hipGetLastError());
     RT_HIP(hipEventRecord(ctx->ev1, ctx->stream));
     return RT_OK;
@@ -811,8 +900,11 @@ extern "C" int rt_get_counters(rt_ctx *ctx, rt_counters *out) {
     if (!ctx || !out) return RT_ERR_INVALID;
     RT_HIP(hipSetDevice(ctx->device));
     RT_HIP(hipStreamSynchronize(ctx->stream));
-    unsigned long long c[kNumCounters];
-    RT_HIP(hipMemcpy(c, ctx->d_counters, sizeof c, hipMemcpyDeviceToHost));
+    std::vector<unsigned long long> all((size_t)kCounterStripes * kCounterStride);
+    RT_HIP(hipMemcpy(all.data(), ctx->d_counters, all.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    unsigned long long c[kNumCounters] = {};
+    for (int st = 0; st < kCounterStripes; st++)
+        for (int i = 0; i < kNumCounters; i++) c[i] += all[(size_t)st * kCounterStride + i];
     std::memset(out, 0, sizeof *out);
     out->rays_primary = c[0]; out->rays_shadow = c[1]; out->rays_secondary = c[2];
     out->tri_tests = c[3]; out->box_tests = c[4]; out->gate_tests = c[5]; out->quadric_tests = c[6];
@@ -828,7 +920,7 @@ extern "C" int rt_get_counters(rt_ctx *ctx, rt_counters *out) {
 extern "C" int rt_reset_counters(rt_ctx *ctx) {
     if (!ctx) return RT_ERR_INVALID;
     RT_HIP(hipSetDevice(ctx->device));
-    RT_HIP(hipMemsetAsync(ctx->d_counters, 0, kNumCounters * sizeof(unsigned long long), ctx->stream));
+    RT_HIP(hipMemsetAsync(ctx->d_counters, 0, (size_t)kCounterStripes * kCounterStride * sizeof(unsigned long long), ctx->stream));
     return RT_OK;
 }
 

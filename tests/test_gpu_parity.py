@@ -318,3 +318,26 @@ def test_shadow_query_cull_changes_nothing(kind):
     assert np.array_equal(frame, lbvh_brute, equal_nan=True)
     lit = frame.reshape(-1, 3).sum(axis=1)
     assert (lit > 0).mean() > 0.5 and np.unique(np.round(lit, 3)).size > 50  # a real picture with shading and shadows
+
+
+@pytest.mark.parametrize("preset,mode,grid", [("teapot", rt.MODE_GRID, 4), ("analytic", rt.MODE_REF_AA9, 1), ("analytic", rt.MODE_REF_1SPP, 1),
+                                              ("textured", rt.MODE_GRID, 3), ("shells", rt.MODE_GRID, 8), ("teapot", rt.MODE_GRID, 7)])
+def test_tap_splitting_kernel_is_bit_identical(preset, mode, grid, host_scene, monkeypatch):
+    """k_render_split (a pixel's taps spread over the four waves of a block, summed in tap order by one
+    wave) against k_render (one lane per pixel): the same frame bit for bit, for tap counts that do and
+    do not divide by four, fill less than one round (32 taps) or need several."""
+    w, h = 88, 50  # not a multiple of the tile size
+    frames = []
+    for min_taps in ("1", "100000"):
+        monkeypatch.setenv("RT_SPLIT_MIN_TAPS", min_taps)
+        ctx = rt.Context(0)
+        ctx.upload(host_scene(preset))
+        frames.append(ctx.render(w, h, mode=mode, grid_m=grid, max_depth=6))
+        ctx.reset_counters()
+        ctx.render(w, h, mode=mode, grid_m=grid, max_depth=6, count_work=True)
+        frames.append(ctx.counters().rays)
+        ctx.close()
+    (split, split8), split_rays, (plain, plain8), plain_rays = frames
+    assert np.array_equal(split, plain, equal_nan=True) and np.array_equal(split8, plain8)
+    assert split_rays == plain_rays
+    assert plain8.std() > 5  # a picture, not a constant
