@@ -1026,6 +1026,33 @@ struct ShadeCtx {
     bool from_outside;
 };
 
+// While the shadow queries of a hit are traced its ShadeCtx is parked in per-lane storage supplied by
+// the Stack policy (LDS columns on the GPU: cold_put(slot, float) / cold_get(slot)), so that it holds no
+// registers during the traversal; without this the 96-register build of the render kernel spilled to
+// scratch memory.
+constexpr int kColdSlots = 22;
+RT_HD float i2f(int32_t i) { return u2f((uint32_t)i); }
+template <class Stack>
+RT_HD void cold_put3(Stack &stk, int slot, v3 v) { stk.cold_put(slot, v.x); stk.cold_put(slot + 1, v.y); stk.cold_put(slot + 2, v.z); }
+template <class Stack>
+RT_HD v3 cold_get3(Stack &stk, int slot) { return V3(stk.cold_get(slot), stk.cold_get(slot + 1), stk.cold_get(slot + 2)); }
+enum : int { kColdPoint = 0, kColdNormal = 3, kColdDirIn = 6, kColdView = 9, kColdColor = 12, kColdDc = 15, kColdOcclusion = 18,
+             kColdShininess = 19, kColdMaterial = 20, kColdOutside = 21 };
+template <class Stack>
+RT_HD void park_shade(Stack &stk, const ShadeCtx &sc) {
+    cold_put3(stk, kColdPoint, sc.point); cold_put3(stk, kColdNormal, sc.normal); cold_put3(stk, kColdDirIn, sc.d_in);
+    cold_put3(stk, kColdView, sc.view); cold_put3(stk, kColdColor, sc.color); cold_put3(stk, kColdDc, sc.dc);
+    stk.cold_put(kColdOcclusion, u2f(sc.occlusion_px)); stk.cold_put(kColdShininess, sc.shininess);
+    stk.cold_put(kColdMaterial, i2f(sc.material)); stk.cold_put(kColdOutside, sc.from_outside ? 1.0f : 0.0f);
+}
+template <class Stack>
+RT_HD void unpark_shade(Stack &stk, ShadeCtx &sc) {
+    sc.point = cold_get3(stk, kColdPoint); sc.normal = cold_get3(stk, kColdNormal); sc.d_in = cold_get3(stk, kColdDirIn);
+    sc.view = cold_get3(stk, kColdView); sc.color = cold_get3(stk, kColdColor); sc.dc = cold_get3(stk, kColdDc);
+    sc.occlusion_px = (uint32_t)f2i(stk.cold_get(kColdOcclusion)); sc.shininess = stk.cold_get(kColdShininess);
+    sc.material = f2i(stk.cold_get(kColdMaterial)); sc.from_outside = stk.cold_get(kColdOutside) != 0.0f;
+}
+
 template <int F, bool COUNT>
 RT_HD void shade_begin(const DevScene &S, const Surf &s, v3 d_in, ShadeCtx &sc, Work &wk) {
     const rt_material &m = S.materials[s.material];
@@ -1094,7 +1121,7 @@ RT_HD v3 shade_end(const DevScene &S, const ShadeCtx &sc, Work &wk) {
 struct Pending { v3 o, d; float w; int32_t depth; };
 
 template <int F, bool COUNT, class Stack>
-RT_HD void shade_lights(const DevScene &S, ShadeCtx &sc, bool hit, int accel, Stack &stk, Work &wk);
+RT_HD void shade_lights(const DevScene &S, bool hit, int accel, Stack &stk, Work &wk);
 
 // The same for scenes without reflective or refractive materials, where every primary ray ends in
 // direct lighting: primary query, then one shadow query per light, as plain nested loops.  The lanes
@@ -1114,28 +1141,36 @@ RT_HD void trace_loop_direct(const DevScene &S, int accel, Stack &stk, Work &wk,
         if (hit) resolve<F, COUNT>(S, c, o, d, s, wk);
         rt_hit_record *fh = src.first_hit();
         if (fh && live) fill_hit(*fh, c, s);
-        ShadeCtx sc;
-        sc.point = V3(NAN, NAN, NAN);
-        if (hit) shade_begin<F, COUNT>(S, s, d, sc, wk);
-        shade_lights<F, COUNT>(S, sc, hit, accel, stk, wk);
+        {
+            ShadeCtx sc;
+            sc.point = V3(NAN, NAN, NAN);
+            if (hit) shade_begin<F, COUNT>(S, s, d, sc, wk);
+            if (hit) park_shade(stk, sc); else cold_put3(stk, kColdPoint, sc.point);
+        }
+        shade_lights<F, COUNT>(S, hit, accel, stk, wk);
         v3 radiance = V3(0, 0, 0);
-        if (hit) radiance = radiance + shade_end<F, COUNT>(S, sc, wk) * 1.0f;
+        if (hit) {
+            ShadeCtx sc;
+            unpark_shade(stk, sc);
+            radiance = radiance + shade_end<F, COUNT>(S, sc, wk) * 1.0f;
+        }
         if (live) src.done(radiance);
         live = live && src.next(o, d);
     }
 }
 
-// One shadow query per light for the hit in `sc` (main.cpp:650-685), for all lanes of the wave in
-// step: the light index is wave-uniform.  A lane without a hit (`hit` false, sc.point NaN) sends NaN
-// rays, which miss everything at no cost.
+// One shadow query per light for the parked hit (main.cpp:650-685), for all lanes of the wave in
+// step: the light index is wave-uniform.  A lane without a hit (`hit` false, parked point NaN) sends
+// NaN rays, which miss everything at no cost.
 template <int F, bool COUNT, class Stack>
-RT_HD void shade_lights(const DevScene &S, ShadeCtx &sc, bool hit, int accel, Stack &stk, Work &wk) {
+RT_HD void shade_lights(const DevScene &S, bool hit, int accel, Stack &stk, Work &wk) {
     const int32_t n_lights = S.n_lights;
     for (int32_t l = 0; l < n_lights; l++) {
         // shadow ray (main.cpp:650-656): from point + EPS * L towards light l
+        v3 point = cold_get3(stk, kColdPoint);
         v3 lp = ld3(S.light_pos + 3 * l);
-        v3 L = normalize(lp - sc.point);
-        float light_r = distance(sc.point, lp);
+        v3 L = normalize(lp - point);
+        float light_r = distance(point, lp);
         Closest cs;
         cs.distance = INFINITY;
         bool query = true;
@@ -1149,10 +1184,15 @@ RT_HD void shade_lights(const DevScene &S, ShadeCtx &sc, bool hit, int accel, St
             query = wave_ballot(near_mesh) != 0;  // nothing can lie between these points and the light
         }
         // |L| = 1, so the local ray parameter equals the world distance up to rounding: clip there
-        if (query) find_closest<F, COUNT>(S, sc.point + L * kEps, L, accel, l, light_r * 1.001f + 1e-3f, light_r, cs, stk, wk);
+        if (query) find_closest<F, COUNT>(S, point + L * kEps, L, accel, l, light_r * 1.001f + 1e-3f, light_r, cs, stk, wk);
         if (hit) {
             wk.rays_shadow++;
-            if (!(cs.distance < light_r)) shade_light<COUNT>(S, sc, l, L, light_r, wk);
+            if (!(cs.distance < light_r)) {
+                ShadeCtx sc;
+                unpark_shade(stk, sc);
+                shade_light<COUNT>(S, sc, l, L, light_r, wk);
+                cold_put3(stk, kColdColor, sc.color);
+            }
         }
     }
 }
@@ -1184,11 +1224,16 @@ RT_HD void trace_loop(const DevScene &S, int max_depth, int accel, Stack &stk, W
             if (fh) fill_hit(*fh, c, s);
         }
         primary = false;
-        ShadeCtx sc;
-        sc.point = V3(NAN, NAN, NAN);
-        if (hit) shade_begin<F, COUNT>(S, s, d, sc, wk);
-        shade_lights<F, COUNT>(S, sc, hit, accel, stk, wk);
+        {
+            ShadeCtx sc;
+            sc.point = V3(NAN, NAN, NAN);
+            if (hit) shade_begin<F, COUNT>(S, s, d, sc, wk);
+            if (hit) park_shade(stk, sc); else cold_put3(stk, kColdPoint, sc.point);
+        }
+        shade_lights<F, COUNT>(S, hit, accel, stk, wk);
         if (hit) {
+            ShadeCtx sc;
+            unpark_shade(stk, sc);
             const rt_material &m = S.materials[sc.material];
             v3 local = shade_end<F, COUNT>(S, sc, wk);
             float refl = m.reflectiveness, refr = m.refractiveness;

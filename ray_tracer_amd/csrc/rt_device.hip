@@ -39,13 +39,18 @@ constexpr int kCounterStripes = 4096, kCounterStride = 16;
 // words each.  All lanes write / read the same words (a broadcast access); the values are made
 // scalar again with readfirstlane.
 // Resident waves per SIMD a render kernel variant is compiled for (register budget 512 / waves).
-// The mesh-only and the quadric-only variants fit 96 registers with few or no spills and gain from
-// the fifth wave; the others would spill heavily there.
-constexpr int render_waves(int features, bool count) { return (features == F_MESH || features == (F_QUADRIC | F_SECONDARY)) && !count ? 5 : 4; }
+// The mesh-only variant fits 96 registers and the quadric-only variant 80 without spilling (a sixth wave did not pay); the
+// others need more than 100.
+constexpr int render_waves(int features, bool count) {
+    return count ? 4 : features == F_MESH ? 5 : features == (F_QUADRIC | F_SECONDARY) ? 5 : 4;
+}
 constexpr int kWavesPerBlock = kBlock / 64;
 constexpr int kStackWords = 3 * kStackDepth;
 struct WaveStack {
     uint32_t *base;  // this wave's kStackWords words of LDS
+    float *cold;     // this thread's column of the block's [kColdSlots][kBlock] parking area
+    __device__ __forceinline__ void cold_put(int slot, float v) { cold[slot * kBlock] = v; }
+    __device__ __forceinline__ float cold_get(int slot) const { return cold[slot * kBlock]; }
     __device__ __forceinline__ void put(int slot, int32_t node, uint64_t mask) {
         if (slot < kStackDepth) {  // never false: the tree height is validated at build time
             base[3 * slot] = (uint32_t)node; base[3 * slot + 1] = (uint32_t)mask; base[3 * slot + 2] = (uint32_t)(mask >> 32);
@@ -59,8 +64,10 @@ struct WaveStack {
 };
 #define RT_WAVE_STACK(name)                                              \
     __shared__ uint32_t name##_lds[kWavesPerBlock * kStackWords];        \
+    __shared__ float name##_cold[kColdSlots * kBlock];                   \
     WaveStack name;                                                      \
-    name.base = name##_lds + (threadIdx.x >> 6) * kStackWords
+    name.base = name##_lds + (threadIdx.x >> 6) * kStackWords;           \
+    name.cold = name##_cold + threadIdx.x
 
 __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -196,7 +203,7 @@ __global__ __launch_bounds__(kBlock, render_waves(F, COUNT)) void k_render(DevSc
 // the pixel sums in tap order, exactly as the one-lane-per-pixel kernel does.  With many taps per
 // pixel this bounds the time of the most expensive block to a quarter, which is what limits frames
 // whose cost is concentrated in few pixels.
-constexpr int kRoundTaps = 32;
+constexpr int kRoundTaps = 16;
 struct TapSlice {  // a trace_loop source: taps [k, k_end) of one pixel
     Camera cam;
     int mode, grid_m, i, j, k, k_end, base;
@@ -217,7 +224,7 @@ struct TapSlice {  // a trace_loop source: taps [k, k_end) of one pixel
 };
 
 template <int F, bool COUNT>
-__global__ __launch_bounds__(kBlock, render_waves(F, COUNT)) void k_render_split(DevScene S, RenderArgs a, float *rgb_tiles,
+__global__ __launch_bounds__(kBlock, 4) void k_render_split(DevScene S, RenderArgs a, float *rgb_tiles,
                                                                                  uint8_t *rgb8_tiles, unsigned long long *counters) {
     RT_WAVE_STACK(stk);
     __shared__ float tap_lds[kRoundTaps * 3 * 64];

@@ -22,6 +22,9 @@ struct VecStack {  // the host build's "wave" is one lane
     int32_t node[kStackDepth];
     uint64_t mask[kStackDepth];
     int max_sp = 0;
+    float cold[kColdSlots];
+    void cold_put(int slot, float v) { cold[slot] = v; }
+    float cold_get(int slot) const { return cold[slot]; }
     void put(int slot, int32_t n, uint64_t m) { if (slot < kStackDepth) { node[slot] = n; mask[slot] = m; if (slot + 1 > max_sp) max_sp = slot + 1; } }
     void get(int slot, int32_t &n, uint64_t &m) { n = node[slot]; m = mask[slot]; }
 };
