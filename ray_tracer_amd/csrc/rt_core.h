@@ -1030,27 +1030,32 @@ struct ShadeCtx {
 // the Stack policy (LDS columns on the GPU: cold_put(slot, float) / cold_get(slot)), so that it holds no
 // registers during the traversal; without this the 96-register build of the render kernel spilled to
 // scratch memory.
-constexpr int kColdSlots = 22;
+constexpr int kColdSlots = 26;  // 22 without secondary rays: see cold_slots()
 RT_HD float i2f(int32_t i) { return u2f((uint32_t)i); }
 template <class Stack>
 RT_HD void cold_put3(Stack &stk, int slot, v3 v) { stk.cold_put(slot, v.x); stk.cold_put(slot + 1, v.y); stk.cold_put(slot + 2, v.z); }
 template <class Stack>
 RT_HD v3 cold_get3(Stack &stk, int slot) { return V3(stk.cold_get(slot), stk.cold_get(slot + 1), stk.cold_get(slot + 2)); }
-enum : int { kColdPoint = 0, kColdNormal = 3, kColdDirIn = 6, kColdView = 9, kColdColor = 12, kColdDc = 15, kColdOcclusion = 18,
-             kColdShininess = 19, kColdMaterial = 20, kColdOutside = 21 };
-template <class Stack>
+enum : int { kColdPoint = 0, kColdNormal = 3, kColdView = 6, kColdColor = 9, kColdDc = 12, kColdOcclusion = 15, kColdShininess = 16,
+             kColdMaterial = 17, kColdL = 18, kColdLightR = 21, kColdDirIn = 22, kColdOutside = 25 };
+// d_in and from_outside only matter for reflection / refraction: the last four slots
+constexpr int cold_slots(int features) { return (features & F_SECONDARY) ? kColdSlots : kColdDirIn; }
+template <int F, class Stack>
 RT_HD void park_shade(Stack &stk, const ShadeCtx &sc) {
-    cold_put3(stk, kColdPoint, sc.point); cold_put3(stk, kColdNormal, sc.normal); cold_put3(stk, kColdDirIn, sc.d_in);
+    cold_put3(stk, kColdPoint, sc.point); cold_put3(stk, kColdNormal, sc.normal);
     cold_put3(stk, kColdView, sc.view); cold_put3(stk, kColdColor, sc.color); cold_put3(stk, kColdDc, sc.dc);
     stk.cold_put(kColdOcclusion, u2f(sc.occlusion_px)); stk.cold_put(kColdShininess, sc.shininess);
-    stk.cold_put(kColdMaterial, i2f(sc.material)); stk.cold_put(kColdOutside, sc.from_outside ? 1.0f : 0.0f);
+    stk.cold_put(kColdMaterial, i2f(sc.material));
+    if (F & F_SECONDARY) { cold_put3(stk, kColdDirIn, sc.d_in); stk.cold_put(kColdOutside, sc.from_outside ? 1.0f : 0.0f); }
 }
-template <class Stack>
+template <int F, class Stack>
 RT_HD void unpark_shade(Stack &stk, ShadeCtx &sc) {
-    sc.point = cold_get3(stk, kColdPoint); sc.normal = cold_get3(stk, kColdNormal); sc.d_in = cold_get3(stk, kColdDirIn);
+    sc.point = cold_get3(stk, kColdPoint); sc.normal = cold_get3(stk, kColdNormal);
     sc.view = cold_get3(stk, kColdView); sc.color = cold_get3(stk, kColdColor); sc.dc = cold_get3(stk, kColdDc);
     sc.occlusion_px = (uint32_t)f2i(stk.cold_get(kColdOcclusion)); sc.shininess = stk.cold_get(kColdShininess);
-    sc.material = f2i(stk.cold_get(kColdMaterial)); sc.from_outside = stk.cold_get(kColdOutside) != 0.0f;
+    sc.material = f2i(stk.cold_get(kColdMaterial));
+    sc.d_in = V3(0, 0, 0); sc.from_outside = true;
+    if (F & F_SECONDARY) { sc.d_in = cold_get3(stk, kColdDirIn); sc.from_outside = stk.cold_get(kColdOutside) != 0.0f; }
 }
 
 template <int F, bool COUNT>
@@ -1145,13 +1150,13 @@ RT_HD void trace_loop_direct(const DevScene &S, int accel, Stack &stk, Work &wk,
             ShadeCtx sc;
             sc.point = V3(NAN, NAN, NAN);
             if (hit) shade_begin<F, COUNT>(S, s, d, sc, wk);
-            if (hit) park_shade(stk, sc); else cold_put3(stk, kColdPoint, sc.point);
+            if (hit) park_shade<F>(stk, sc); else cold_put3(stk, kColdPoint, sc.point);
         }
         shade_lights<F, COUNT>(S, hit, accel, stk, wk);
         v3 radiance = V3(0, 0, 0);
         if (hit) {
             ShadeCtx sc;
-            unpark_shade(stk, sc);
+            unpark_shade<F>(stk, sc);
             radiance = radiance + shade_end<F, COUNT>(S, sc, wk) * 1.0f;
         }
         if (live) src.done(radiance);
@@ -1184,12 +1189,16 @@ RT_HD void shade_lights(const DevScene &S, bool hit, int accel, Stack &stk, Work
             query = wave_ballot(near_mesh) != 0;  // nothing can lie between these points and the light
         }
         // |L| = 1, so the local ray parameter equals the world distance up to rounding: clip there
-        if (query) find_closest<F, COUNT>(S, point + L * kEps, L, accel, l, light_r * 1.001f + 1e-3f, light_r, cs, stk, wk);
+        if (query) {
+            cold_put3(stk, kColdL, L); stk.cold_put(kColdLightR, light_r);
+            find_closest<F, COUNT>(S, point + L * kEps, L, accel, l, light_r * 1.001f + 1e-3f, light_r, cs, stk, wk);
+            L = cold_get3(stk, kColdL); light_r = stk.cold_get(kColdLightR);
+        }
         if (hit) {
             wk.rays_shadow++;
             if (!(cs.distance < light_r)) {
                 ShadeCtx sc;
-                unpark_shade(stk, sc);
+                unpark_shade<F>(stk, sc);
                 shade_light<COUNT>(S, sc, l, L, light_r, wk);
                 cold_put3(stk, kColdColor, sc.color);
             }
@@ -1228,12 +1237,12 @@ RT_HD void trace_loop(const DevScene &S, int max_depth, int accel, Stack &stk, W
             ShadeCtx sc;
             sc.point = V3(NAN, NAN, NAN);
             if (hit) shade_begin<F, COUNT>(S, s, d, sc, wk);
-            if (hit) park_shade(stk, sc); else cold_put3(stk, kColdPoint, sc.point);
+            if (hit) park_shade<F>(stk, sc); else cold_put3(stk, kColdPoint, sc.point);
         }
         shade_lights<F, COUNT>(S, hit, accel, stk, wk);
         if (hit) {
             ShadeCtx sc;
-            unpark_shade(stk, sc);
+            unpark_shade<F>(stk, sc);
             const rt_material &m = S.materials[sc.material];
             v3 local = shade_end<F, COUNT>(S, sc, wk);
             float refl = m.reflectiveness, refr = m.refractiveness;

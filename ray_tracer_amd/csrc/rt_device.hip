@@ -62,9 +62,9 @@ struct WaveStack {
         mask = ((uint64_t)hi << 32) | lo;
     }
 };
-#define RT_WAVE_STACK(name)                                              \
+#define RT_WAVE_STACK(name, features)                                    \
     __shared__ uint32_t name##_lds[kWavesPerBlock * kStackWords];        \
-    __shared__ float name##_cold[kColdSlots * kBlock];                   \
+    __shared__ float name##_cold[cold_slots(features) * kBlock];         \
     WaveStack name;                                                      \
     name.base = name##_lds + (threadIdx.x >> 6) * kStackWords;           \
     name.cold = name##_cold + threadIdx.x
@@ -176,7 +176,7 @@ __global__ void k_octant_variants(BvhNode *nodes, int n) {
 template <int F, bool COUNT>
 __global__ __launch_bounds__(kBlock, render_waves(F, COUNT)) void k_render(DevScene S, RenderArgs a, float *rgb_tiles, uint8_t *rgb8_tiles,
                                                    unsigned long long *counters) {
-    RT_WAVE_STACK(stk);
+    RT_WAVE_STACK(stk, F);
     int tile = blockIdx.x * a.world_size + a.rank;
     int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     int px = (wave & 1) * 8 + (lane & 7), py = (wave >> 1) * 8 + (lane >> 3);
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(kBlock, render_waves(F, COUNT)) void k_render(DevSc
 // the pixel sums in tap order, exactly as the one-lane-per-pixel kernel does.  With many taps per
 // pixel this bounds the time of the most expensive block to a quarter, which is what limits frames
 // whose cost is concentrated in few pixels.
-constexpr int kRoundTaps = 16;
+constexpr int kRoundTaps = 8;
 struct TapSlice {  // a trace_loop source: taps [k, k_end) of one pixel
     Camera cam;
     int mode, grid_m, i, j, k, k_end, base;
@@ -226,7 +226,7 @@ struct TapSlice {  // a trace_loop source: taps [k, k_end) of one pixel
 template <int F, bool COUNT>
 __global__ __launch_bounds__(kBlock, 4) void k_render_split(DevScene S, RenderArgs a, float *rgb_tiles,
                                                                                  uint8_t *rgb8_tiles, unsigned long long *counters) {
-    RT_WAVE_STACK(stk);
+    RT_WAVE_STACK(stk, F);
     __shared__ float tap_lds[kRoundTaps * 3 * 64];
     int local = blockIdx.x >> 2, quad = blockIdx.x & 3;
     int tile = local * a.world_size + a.rank;
@@ -293,7 +293,7 @@ __global__ void k_untile(const T *shards, T *frame, int width, int height, int t
 __global__ __launch_bounds__(kBlock) void k_trace_rays(DevScene S, long long n, const float *o, const float *d,
                                                        int max_depth, int accel, rt_hit_record *hits, float *radiance,
                                                        unsigned long long *counters) {
-    RT_WAVE_STACK(stk);
+    RT_WAVE_STACK(stk, F_ALL);
     long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     Work wk;
     work_zero(wk);
@@ -308,7 +308,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_rays(DevScene S, long long n, 
 
 __global__ __launch_bounds__(kBlock) void k_intersect_object(DevScene S, int object, long long n, const float *o,
                                                              const float *d, int accel, rt_hit_record *hits) {
-    RT_WAVE_STACK(stk);
+    RT_WAVE_STACK(stk, F_ALL);
     long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n) return;
     Work wk;

@@ -325,7 +325,7 @@ def test_shadow_query_cull_changes_nothing(kind):
 def test_tap_splitting_kernel_is_bit_identical(preset, mode, grid, host_scene, monkeypatch):
     """k_render_split (a pixel's taps spread over the four waves of a block, summed in tap order by one
     wave) against k_render (one lane per pixel): the same frame bit for bit, for tap counts that do and
-    do not divide by four, fill less than one round (16 taps) or need several."""
+    do not divide by four, fill less than one round (8 taps) or need several."""
     w, h = 88, 50  # not a multiple of the tile size
     frames = []
     for min_taps in ("1", "100000"):
