@@ -107,17 +107,19 @@ __global__ void k_bitonic_step(unsigned long long *keys, int n_pow2, int j, int 
     }
 }
 
-// sorted position -> triangle record, tie-break key and original index (keys == nullptr: identity order)
-__global__ void k_gather_tris(const unsigned long long *keys, int n, int tri_offset, const float *tri_pos,
-                              const int32_t *tri_frag, const int32_t *tri_sub, f4 *tri_test, uint32_t *tri_key,
-                              int32_t *tri_orig) {
+// sorted position -> triangle record, tie-break key, original triangle and leaf box of the reference
+// at that position (keys == nullptr: identity order)
+__global__ void k_gather_tris(const unsigned long long *keys, int n, int ref_offset, const float *ref_pos, const int32_t *ref_tri,
+                              const float *tri_pos, const int32_t *tri_frag, const int32_t *tri_sub, f4 *tri_test,
+                              uint32_t *tri_key, int32_t *tri_orig, float *leaf_box) {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     int local = keys ? (int)(uint32_t)(keys[k] & 0xffffffffull) : k;
-    int orig = tri_offset + local;
-    make_tri_test(tri_pos + 9 * (size_t)orig, tri_test + 3 * (size_t)(tri_offset + k));
-    tri_key[tri_offset + k] = 2u * (uint32_t)tri_frag[orig] + (1u - (uint32_t)tri_sub[orig]);
-    tri_orig[tri_offset + k] = orig;
+    int orig = ref_tri[ref_offset + local];
+    make_tri_test(tri_pos + 9 * (size_t)orig, tri_test + 3 * (size_t)(ref_offset + k));
+    tri_key[ref_offset + k] = 2u * (uint32_t)tri_frag[orig] + (1u - (uint32_t)tri_sub[orig]);
+    tri_orig[ref_offset + k] = orig;
+    piece_box(ref_pos + 9 * (size_t)(ref_offset + local), leaf_box + 6 * (size_t)(ref_offset + k));
 }
 
 __global__ void k_children(const unsigned long long *keys, int n, int32_t *c0, int32_t *c1) {
@@ -132,7 +134,7 @@ __global__ void k_children(const unsigned long long *keys, int n, int32_t *c0, i
 // Bottom-up fit by ONE workgroup: pass p completes every node whose children were completed in an
 // earlier pass; done_pass[i] holds the pass number (0 = not yet).  All traffic stays inside one CU,
 // so a workgroup barrier is enough to order a pass after the previous one.
-__global__ __launch_bounds__(1024) void k_fit(int n, const int32_t *c0s, const int32_t *c1s, const f4 *tt, float pad,
+__global__ __launch_bounds__(1024) void k_fit(int n, const int32_t *c0s, const int32_t *c1s, const float *leaf_box, float pad,
                                               int32_t *done_pass, float *node_lo, float *node_hi, int32_t *height,
                                               BvhNode *nodes, int32_t *root_height) {
     __shared__ int s_left;
@@ -144,7 +146,7 @@ __global__ __launch_bounds__(1024) void k_fit(int n, const int32_t *c0s, const i
         __syncthreads();
         int left = 0;
         for (int i = threadIdx.x; i < n_int; i += blockDim.x)
-            if (lbvh_fit_node(i, pass, c0s, c1s, tt, pad, done_pass, node_lo, node_hi, height, nodes) == 2) left++;
+            if (lbvh_fit_node(i, pass, c0s, c1s, leaf_box, pad, done_pass, node_lo, node_hi, height, nodes) == 2) left++;
         if (left) atomicAdd(&s_left, left);
         __threadfence_block();
         __syncthreads();
@@ -337,6 +339,10 @@ struct rt_ctx {
     std::vector<int32_t> mesh_ranges;  // (tri_offset, tri_count) of every uploaded mesh
     // device arrays the build writes
     float *d_tri_pos = nullptr;
+    float *d_ref_pos = nullptr;    // 9 floats per reference (a piece of a triangle), in cutting order
+    int32_t *d_ref_tri = nullptr;  // the triangle each reference is a piece of
+    float *d_leaf_box = nullptr;   // lo, hi of the reference at each sorted position
+    int n_refs = 0;
     f4 *d_tri_test = nullptr;
     uint32_t *d_tri_key = nullptr;
     int32_t *d_tri_orig = nullptr;
@@ -469,9 +475,6 @@ extern "C" int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *sc) {
     if ((rc = dev_alloc(ctx, &d_tmat, nt, sc->tri_material))) return rc;
     if ((rc = dev_alloc(ctx, &ctx->d_tri_frag, nt, sc->tri_frag))) return rc;
     if ((rc = dev_alloc(ctx, &ctx->d_tri_sub, nt, sc->tri_sub))) return rc;
-    if ((rc = dev_alloc(ctx, &ctx->d_tri_test, 3 * nt, (const void *)nullptr))) return rc;
-    if ((rc = dev_alloc(ctx, &ctx->d_tri_key, nt, (const void *)nullptr))) return rc;
-    if ((rc = dev_alloc(ctx, &ctx->d_tri_orig, nt, (const void *)nullptr))) return rc;
 
     // textures
     std::vector<DevTexture> tex(sc->n_textures);
@@ -517,8 +520,18 @@ extern "C" int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *sc) {
     ctx->n_meshes = sc->n_meshes;
     ctx->n_triangles = sc->n_triangles;
     std::vector<f4> gate;
-    int node_total = prepare_meshes(sc, ctx->meshes, ctx->mesh_build, gate);
+    std::vector<float> ref_pos;
+    std::vector<int32_t> ref_tri;
+    int node_total = prepare_meshes(sc, ctx->meshes, ctx->mesh_build, gate, true, ref_pos, ref_tri);
     for (int i = 0; i < sc->n_meshes; i++) ctx->meshes[i].object = mesh_obj[i];
+    size_t nr = ref_tri.size();
+    ctx->n_refs = (int)nr;
+    if ((rc = dev_alloc(ctx, &ctx->d_ref_pos, 9 * nr, ref_pos.data()))) return rc;
+    if ((rc = dev_alloc(ctx, &ctx->d_ref_tri, nr, ref_tri.data()))) return rc;
+    if ((rc = dev_alloc(ctx, &ctx->d_leaf_box, 6 * nr, (const void *)nullptr))) return rc;
+    if ((rc = dev_alloc(ctx, &ctx->d_tri_test, 3 * nr, (const void *)nullptr))) return rc;
+    if ((rc = dev_alloc(ctx, &ctx->d_tri_key, nr, (const void *)nullptr))) return rc;
+    if ((rc = dev_alloc(ctx, &ctx->d_tri_orig, nr, (const void *)nullptr))) return rc;
     ctx->n_nodes = node_total;
     f4 *d_gate;
     if ((rc = dev_alloc(ctx, &d_gate, gate.size(), gate.data()))) return rc;
@@ -531,11 +544,11 @@ extern "C" int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *sc) {
 
     // identity triangle order: valid for RT_ACCEL_BRUTE until rt_build_accel sorts it
     for (int i = 0; i < sc->n_meshes; i++) {
-        const rt_mesh &m = sc->meshes[i];
+        const DevMesh &m = ctx->meshes[i];
         if (m.tri_count <= 0) continue;
         hipLaunchKernelGGL(k_gather_tris, dim3((m.tri_count + 255) / 256), dim3(256), 0, ctx->stream, nullptr, m.tri_count,
-                           m.tri_offset, ctx->d_tri_pos, ctx->d_tri_frag, ctx->d_tri_sub, ctx->d_tri_test, ctx->d_tri_key,
-                           ctx->d_tri_orig);
+                           m.tri_offset, ctx->d_ref_pos, ctx->d_ref_tri, ctx->d_tri_pos, ctx->d_tri_frag, ctx->d_tri_sub,
+                           ctx->d_tri_test, ctx->d_tri_key, ctx->d_tri_orig, ctx->d_leaf_box);
     }
     RT_HIP(hipGetLastError());
 
@@ -611,9 +624,11 @@ extern "C" int rt_scene_update(rt_ctx *ctx, const rt_scene_desc *sc) {
     S.n_axis_planes = (int32_t)axis_planes.size(); S.n_gen_planes = (int32_t)gen_planes.size();
     // mesh records: new maps, gate boxes and world bounds; triangle and node ranges are unchanged
     std::vector<DevMesh> meshes;
-    std::vector<MeshBuild> build;
+    std::vector<MeshBuild> build = ctx->mesh_build;  // the reference ranges stay
     std::vector<f4> gate;
-    prepare_meshes(sc, meshes, build, gate);
+    std::vector<float> no_pos;
+    std::vector<int32_t> no_tri;
+    prepare_meshes(sc, meshes, build, gate, false, no_pos, no_tri);
     for (int i = 0; i < sc->n_meshes; i++) {
         meshes[i].object = mesh_obj[i];
         if (meshes[i].node_offset != ctx->meshes[i].node_offset) return fail(ctx, RT_ERR_STATE, "rt_scene_update: node layout changed");
@@ -672,17 +687,18 @@ extern "C" int rt_build_accel(rt_ctx *ctx) {
         int n_pow2 = 1;
         while (n_pow2 < n) n_pow2 <<= 1;
         dim3 blk(256), grd((n_pow2 + 255) / 256);
-        hipLaunchKernelGGL(k_sort_keys, grd, blk, 0, ctx->stream, ctx->d_tri_pos + 9 * (size_t)m.tri_offset, n, n_pow2,
+        hipLaunchKernelGGL(k_sort_keys, grd, blk, 0, ctx->stream, ctx->d_ref_pos + 9 * (size_t)m.tri_offset, n, n_pow2,
                            d_bounds + 6 * i, d_bounds + 6 * i + 3, d_keys);
         for (int k = 2; k <= n_pow2; k <<= 1)
             for (int j = k >> 1; j > 0; j >>= 1)
                 hipLaunchKernelGGL(k_bitonic_step, grd, blk, 0, ctx->stream, d_keys, n_pow2, j, k);
-        hipLaunchKernelGGL(k_gather_tris, dim3((n + 255) / 256), blk, 0, ctx->stream, d_keys, n, m.tri_offset, ctx->d_tri_pos,
-                           ctx->d_tri_frag, ctx->d_tri_sub, ctx->d_tri_test, ctx->d_tri_key, ctx->d_tri_orig);
+        hipLaunchKernelGGL(k_gather_tris, dim3((n + 255) / 256), blk, 0, ctx->stream, d_keys, n, m.tri_offset, ctx->d_ref_pos,
+                           ctx->d_ref_tri, ctx->d_tri_pos, ctx->d_tri_frag, ctx->d_tri_sub, ctx->d_tri_test, ctx->d_tri_key,
+                           ctx->d_tri_orig, ctx->d_leaf_box);
         if (n >= 2) {
             hipLaunchKernelGGL(k_children, dim3((n + 255) / 256), blk, 0, ctx->stream, d_keys, n, d_c0, d_c1);
             hipLaunchKernelGGL(k_fit, dim3(1), dim3(1024), 0, ctx->stream, n, d_c0, d_c1,
-                               ctx->d_tri_test + 3 * (size_t)m.tri_offset, ctx->mesh_build[i].pad, d_done, d_lo, d_hi, d_height,
+                               ctx->d_leaf_box + 6 * (size_t)m.tri_offset, ctx->mesh_build[i].pad, d_done, d_lo, d_hi, d_height,
                                ctx->d_nodes + m.node_offset, d_root + i);
             int nv = (n - 1) * (kOctants - 1);
             hipLaunchKernelGGL(k_octant_variants, dim3((nv + 255) / 256), blk, 0, ctx->stream, ctx->d_nodes + m.node_offset, n - 1);

@@ -87,21 +87,24 @@ RT_HD void lbvh_node_children(const uint64_t *keys, int n, int i, int32_t &c0, i
     c1 = (last == gamma + 1) ? ~(gamma + 1) : gamma + 1;
 }
 
-// Bounds of a sorted triangle, grown by `pad` on every side so that the slab test never rejects a
-// ray the exact triangle test accepts.
-RT_HD void tri_bounds(const f4 *tt, int k, float pad, float *lo, float *hi) {
-    f4 A = tt[3 * k], B = tt[3 * k + 1], C = tt[3 * k + 2];
-    float px[3] = {A.x, A.w, B.z}, py[3] = {A.y, B.x, B.w}, pz[3] = {A.z, B.y, C.x};
-    lo[0] = fminf(px[0], fminf(px[1], px[2])) - pad; hi[0] = fmaxf(px[0], fmaxf(px[1], px[2])) + pad;
-    lo[1] = fminf(py[0], fminf(py[1], py[2])) - pad; hi[1] = fmaxf(py[0], fmaxf(py[1], py[2])) + pad;
-    lo[2] = fminf(pz[0], fminf(pz[1], pz[2])) - pad; hi[2] = fmaxf(pz[0], fmaxf(pz[1], pz[2])) + pad;
+// Box of leaf k (a triangle, or one piece of a split triangle: six floats lo, hi), grown by `pad` on
+// every side so that the slab test never rejects a ray the exact triangle test accepts.
+RT_HD void leaf_bounds(const float *leaf_box, int k, float pad, float *lo, float *hi) {
+    for (int a = 0; a < 3; a++) { lo[a] = leaf_box[6 * k + a] - pad; hi[a] = leaf_box[6 * k + 3 + a] + pad; }
+}
+// unpadded box of the triangle (or piece) with vertices p[0..8]
+RT_HD void piece_box(const float *p, float *box) {
+    for (int a = 0; a < 3; a++) {
+        box[a] = fminf(p[a], fminf(p[3 + a], p[6 + a]));
+        box[3 + a] = fmaxf(p[a], fmaxf(p[3 + a], p[6 + a]));
+    }
 }
 
 // One fitting pass over internal node i.  done_pass[i] is 0 until the node is completed and then
 // holds the number of the pass that completed it.  A node may be completed in pass `pass` once each
 // child is a leaf or was completed in an EARLIER pass (so its bounds are already in memory).
 // Returns 0: was already done, 1: completed now, 2: still waiting.
-RT_HD int lbvh_fit_node(int i, int pass, const int32_t *c0s, const int32_t *c1s, const f4 *tt, float pad,
+RT_HD int lbvh_fit_node(int i, int pass, const int32_t *c0s, const int32_t *c1s, const float *leaf_box, float pad,
                         int32_t *done_pass, float *node_lo, float *node_hi, int32_t *height, BvhNode *nodes) {
     if (done_pass[i]) return 0;
     int32_t c0 = c0s[i], c1 = c1s[i];
@@ -110,9 +113,9 @@ RT_HD int lbvh_fit_node(int i, int pass, const int32_t *c0s, const int32_t *c1s,
     if (!(r0 && r1)) return 2;
     BvhNode nd;
     int h0 = 0, h1 = 0;
-    if (c0 < 0) tri_bounds(tt, ~c0, pad, nd.lo0, nd.hi0);
+    if (c0 < 0) leaf_bounds(leaf_box, ~c0, pad, nd.lo0, nd.hi0);
     else { for (int a = 0; a < 3; a++) { nd.lo0[a] = node_lo[3 * c0 + a]; nd.hi0[a] = node_hi[3 * c0 + a]; } h0 = height[c0]; }
-    if (c1 < 0) tri_bounds(tt, ~c1, pad, nd.lo1, nd.hi1);
+    if (c1 < 0) leaf_bounds(leaf_box, ~c1, pad, nd.lo1, nd.hi1);
     else { for (int a = 0; a < 3; a++) { nd.lo1[a] = node_lo[3 * c1 + a]; nd.hi1[a] = node_hi[3 * c1 + a]; } h1 = height[c1]; }
     nd.c0 = c0; nd.c1 = c1; nd.pad0 = 0; nd.pad1 = 0;
     for (int a = 0; a < 3; a++) {

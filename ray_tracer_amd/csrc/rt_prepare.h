@@ -16,10 +16,66 @@ namespace rtc {
 
 struct MeshBuild {
     int node_offset = 0;
+    int ref_offset = 0, ref_count = 0;            // this mesh's leaves in the sorted arrays (>= its triangle count)
     float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};  // bounds of the finite vertices (Morton normalisation)
     float pad = 0;                                // leaf box padding
     int height = 0;                               // LBVH height after the build
 };
+
+// The leaves of a mesh's LBVH ("references").  A triangle whose box is much larger than the mesh's
+// typical triangle is cut into pieces (longest edge halved, recursively) and every piece becomes a
+// leaf of its own with the piece's box; all pieces still test the WHOLE triangle, so a hit is found
+// by whichever piece's box the ray enters and is the same hit.  Long thin triangles -- the
+// reference's OBJ loader makes thousands from vt / vn lines (main.cpp:796-805) -- otherwise have
+// boxes that cover most of the mesh and defeat the tree.
+// ref_pos: 9 floats per reference (the piece), ref_tri: its triangle (index into the scene's arrays).
+inline void split_piece(const float *p, float tau2, int depth, int tri, std::vector<float> &ref_pos, std::vector<int32_t> &ref_tri) {
+    float box[6], d2 = 0;
+    piece_box(p, box);
+    for (int a = 0; a < 3; a++) d2 += (box[3 + a] - box[a]) * (box[3 + a] - box[a]);
+    if (depth <= 0 || !(d2 > tau2) || !std::isfinite(d2)) {
+        ref_pos.insert(ref_pos.end(), p, p + 9);
+        ref_tri.push_back(tri);
+        return;
+    }
+    int e = 0;
+    float best = -1;
+    for (int k = 0; k < 3; k++) {  // edge k: vertex k -> vertex (k + 1) % 3
+        const float *u = p + 3 * k, *v = p + 3 * ((k + 1) % 3);
+        float l2 = (u[0] - v[0]) * (u[0] - v[0]) + (u[1] - v[1]) * (u[1] - v[1]) + (u[2] - v[2]) * (u[2] - v[2]);
+        if (l2 > best) { best = l2; e = k; }
+    }
+    const float *u = p + 3 * e, *v = p + 3 * ((e + 1) % 3), *w = p + 3 * ((e + 2) % 3);
+    float m[3] = {0.5f * (u[0] + v[0]), 0.5f * (u[1] + v[1]), 0.5f * (u[2] + v[2])};
+    float a[9] = {u[0], u[1], u[2], m[0], m[1], m[2], w[0], w[1], w[2]};
+    float b[9] = {m[0], m[1], m[2], v[0], v[1], v[2], w[0], w[1], w[2]};
+    split_piece(a, tau2, depth - 1, tri, ref_pos, ref_tri);
+    split_piece(b, tau2, depth - 1, tri, ref_pos, ref_tri);
+}
+inline void make_mesh_refs(const rt_scene_desc *sc, const rt_mesh &m, std::vector<float> &ref_pos, std::vector<int32_t> &ref_tri) {
+    std::vector<float> diag(std::max(m.tri_count, 0));
+    for (int t = 0; t < m.tri_count; t++) {
+        float box[6], d2 = 0;
+        piece_box(sc->tri_pos + 9 * (size_t)(m.tri_offset + t), box);
+        for (int a = 0; a < 3; a++) d2 += (box[3 + a] - box[a]) * (box[3 + a] - box[a]);
+        diag[t] = std::isfinite(d2) ? d2 : 0.0f;
+    }
+    float tau2 = INFINITY;
+    if (m.tri_count > 0) {
+        std::vector<float> tmp = diag;
+        std::nth_element(tmp.begin(), tmp.begin() + tmp.size() / 2, tmp.end());
+        float median2 = tmp[tmp.size() / 2];
+        if (median2 > 0) tau2 = 16.0f * median2;  // pieces at most 4 x the median triangle's diagonal
+    }
+    for (int attempt = 0;; attempt++) {
+        size_t pos0 = ref_pos.size(), tri0 = ref_tri.size();
+        for (int t = 0; t < m.tri_count; t++)
+            split_piece(sc->tri_pos + 9 * (size_t)(m.tri_offset + t), tau2, 8, m.tri_offset + t, ref_pos, ref_tri);
+        if (ref_tri.size() - tri0 <= 4 * (size_t)m.tri_count + 64 || attempt >= 8) break;
+        ref_pos.resize(pos0); ref_tri.resize(tri0);  // too many pieces: coarser
+        tau2 *= 4.0f;
+    }
+}
 
 // Returns an empty string when the description is consistent, else what is wrong.
 inline std::string validate_scene(const rt_scene_desc *sc) {
@@ -121,10 +177,14 @@ inline void kind_to_object(const rt_scene_desc *sc, std::vector<int32_t> &plane_
 
 // Fills the device-side mesh records (everything but device pointers), the per-mesh build data and
 // the gate triangles (36 f4 per mesh).  Returns the total number of LBVH nodes.
+// refs == true: also cuts the meshes into references (ref_pos, ref_tri); false: the reference ranges in
+// `build` are kept (same geometry, new placement).
 inline int prepare_meshes(const rt_scene_desc *sc, std::vector<DevMesh> &meshes, std::vector<MeshBuild> &build,
-                          std::vector<f4> &gate) {
+                          std::vector<f4> &gate, bool refs, std::vector<float> &ref_pos, std::vector<int32_t> &ref_tri) {
+    std::vector<MeshBuild> previous = build;
     meshes.assign(sc->n_meshes, DevMesh{});
     build.assign(sc->n_meshes, MeshBuild{});
+    if (refs) { ref_pos.clear(); ref_tri.clear(); }
     gate.assign(36 * (size_t)sc->n_meshes, f4{0, 0, 0, 0});
     int node_total = 0;
     for (int i = 0; i < sc->n_meshes; i++) {
@@ -135,11 +195,17 @@ inline int prepare_meshes(const rt_scene_desc *sc, std::vector<DevMesh> &meshes,
         std::memcpy(dm.to_world, m.to_world, sizeof dm.to_world);
         std::memcpy(dm.normal_mat, m.normal_mat, sizeof dm.normal_mat);
         std::memcpy(dm.box_to_local, m.box_to_local, sizeof dm.box_to_local);
-        dm.tri_offset = m.tri_offset; dm.tri_count = m.tri_count; dm.boxed = m.boxed;
+        if (refs) {
+            mb.ref_offset = (int)ref_tri.size();
+            make_mesh_refs(sc, m, ref_pos, ref_tri);
+            mb.ref_count = (int)ref_tri.size() - mb.ref_offset;
+        } else {
+            mb.ref_offset = previous[i].ref_offset; mb.ref_count = previous[i].ref_count;
+        }
+        dm.tri_offset = mb.ref_offset; dm.tri_count = mb.ref_count; dm.boxed = m.boxed;  // what the kernels walk: references
         dm.node_offset = node_total; dm.gate_tri_offset = 12 * i;
-        dm.pad[0] = dm.pad[1] = 0;
         mb.node_offset = node_total;
-        node_total += kOctants * std::max(m.tri_count - 1, 0);  // one copy of the tree per ray-direction octant
+        node_total += kOctants * std::max(mb.ref_count - 1, 0);  // one copy of the tree per ray-direction octant
         float maxabs = 0;
         for (int a = 0; a < 3; a++) { mb.lo[a] = INFINITY; mb.hi[a] = -INFINITY; }
         for (int t = 0; t < m.tri_count; t++) {

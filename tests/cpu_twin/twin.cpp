@@ -45,6 +45,8 @@ struct Twin {
     std::vector<LightCull> light_cull;
     std::vector<AxisPlaneRec> axis_planes;
     std::vector<PlaneRec> gen_planes;
+    std::vector<float> ref_pos, leaf_box;  // pieces the triangles are cut into; boxes of the sorted pieces
+    std::vector<int32_t> ref_tri;
     std::vector<float> tri_pos, tri_nrm, tri_uv, light_pos, light_color;
     std::vector<BvhNode> nodes;
     std::vector<rt_material> materials;
@@ -58,10 +60,11 @@ struct Twin {
 void gather(Twin &t, const DevMesh &m, const std::vector<uint64_t> *keys) {
     for (int k = 0; k < m.tri_count; k++) {
         int local = keys ? (int)(uint32_t)((*keys)[k] & 0xffffffffull) : k;
-        int orig = m.tri_offset + local;
+        int orig = t.ref_tri[m.tri_offset + local];
         make_tri_test(&t.tri_pos[9 * (size_t)orig], &t.tri_test[3 * (size_t)(m.tri_offset + k)]);
         t.tri_key[m.tri_offset + k] = 2u * (uint32_t)t.tri_frag[orig] + (1u - (uint32_t)t.tri_sub[orig]);
         t.tri_orig[m.tri_offset + k] = orig;
+        piece_box(&t.ref_pos[9 * (size_t)(m.tri_offset + local)], &t.leaf_box[6 * (size_t)(m.tri_offset + k)]);
     }
 }
 
@@ -105,10 +108,14 @@ void *twin_create(const rt_scene_desc *sc, char *errbuf, int errcap) {
     for (int i = 0, k = 0; i < sc->n_textures; i++)  // pointers after the outer vector stopped growing
         if (sc->textures[i].kind == RT_TEX_IMAGE) t->textures[i].texels = t->texels[k++].data();
     make_srgb_lut(t->srgb_lut);
-    int node_total = prepare_meshes(sc, t->meshes, t->build, t->gate);
-    t->tri_test.assign(3 * nt, f4{0, 0, 0, 0});
-    t->tri_key.assign(nt, 0);
-    t->tri_orig.assign(nt, 0);
+    int node_total = prepare_meshes(sc, t->meshes, t->build, t->gate, true, t->ref_pos, t->ref_tri);
+    size_t nr = t->ref_tri.size();
+    t->tri_test.assign(3 * nr + 1, f4{0, 0, 0, 0});
+    t->tri_key.assign(nr + 1, 0);
+    t->tri_orig.assign(nr + 1, 0);
+    t->leaf_box.assign(6 * nr + 1, 0.0f);
+    t->ref_pos.push_back(0.0f);
+    t->ref_tri.push_back(0);
     t->nodes.assign(std::max(node_total, 1), BvhNode{});
     for (const DevMesh &m : t->meshes) gather(*t, m, nullptr);
     DevScene &S = t->S;
@@ -144,18 +151,18 @@ int twin_build_accel(void *h) {
         int n = m.tri_count;
         if (n <= 0) continue;
         std::vector<uint64_t> keys(n);
-        for (int i = 0; i < n; i++) keys[i] = tri_sort_key(&t->tri_pos[9 * (size_t)(m.tri_offset + i)], t->build[mi].lo, t->build[mi].hi, (uint32_t)i);
+        for (int i = 0; i < n; i++) keys[i] = tri_sort_key(&t->ref_pos[9 * (size_t)(m.tri_offset + i)], t->build[mi].lo, t->build[mi].hi, (uint32_t)i);
         std::sort(keys.begin(), keys.end());
         gather(*t, m, &keys);
         if (n < 2) continue;
         std::vector<int32_t> c0(n - 1), c1(n - 1), done(n - 1, 0), height(n - 1, 0);
         std::vector<float> lo(3 * (size_t)(n - 1)), hi(3 * (size_t)(n - 1));
         for (int i = 0; i < n - 1; i++) lbvh_node_children(keys.data(), n, i, c0[i], c1[i]);
-        const f4 *tt = &t->tri_test[3 * (size_t)m.tri_offset];
+        const float *leaf_box = &t->leaf_box[6 * (size_t)m.tri_offset];
         for (int pass = 1; pass <= 4096; pass++) {
             int left = 0;
             for (int i = 0; i < n - 1; i++)
-                if (lbvh_fit_node(i, pass, c0.data(), c1.data(), tt, t->build[mi].pad, done.data(), lo.data(), hi.data(), height.data(),
+                if (lbvh_fit_node(i, pass, c0.data(), c1.data(), leaf_box, t->build[mi].pad, done.data(), lo.data(), hi.data(), height.data(),
                                   &t->nodes[m.node_offset]) == 2)
                     left++;
             if (!left) break;
@@ -219,6 +226,9 @@ void twin_render(void *h, const rt_render_params *p, int x0, int y0, int x1, int
         }
     if (counters) for (int k = 0; k < 10; k++) counters[k] += acc[k];
 }
+
+// number of references (leaves) of a mesh's tree
+int twin_ref_count(void *h, int mesh) { return static_cast<Twin *>(h)->meshes[mesh].tri_count; }
 
 int twin_copy_bvh(void *h, int mesh, float *nodes, int32_t *order) {
     Twin *t = static_cast<Twin *>(h);

@@ -121,3 +121,69 @@ def check_rgb8(ref, got, what="", frac=0.999):
     ok = (diff <= 1).mean()
     assert ok >= frac, f"{what}: only {ok:.5f} of the pixels within 1 LSB (worst {diff.max()})"
     return diff
+
+
+def check_lbvh(nodes, order, pos_all, tri_offset, tri_count, max_height=48, seed=0):
+    """Structure of one mesh's LBVH.  `order[k]` is the triangle behind leaf k; a large triangle is cut into
+    pieces and is then behind several leaves, each with the box of its piece.
+    Checked: every triangle is behind at least one leaf and nothing else is; every leaf and every internal
+    node is referenced exactly once; parent boxes enclose their children's; points sampled on a triangle
+    (corners included) lie inside the box of one of its leaves, so a ray that hits the triangle enters one of
+    them.  Returns the height."""
+    n = len(order)
+    assert len(nodes) == max(n - 1, 0)
+    assert n >= tri_count
+    assert sorted(set(int(o) for o in order)) == list(range(tri_offset, tri_offset + tri_count))
+    if n < 2:
+        return 0
+    ch = nodes[:, 12:14].copy().view(np.int32)
+    assert sorted(~ch[ch < 0]) == list(range(n))
+    assert sorted(ch[ch >= 0]) == list(range(1, len(nodes)))
+    box = np.stack([nodes[:, 0:6], nodes[:, 6:12]], axis=1).astype(np.float64)  # [node, side, lo|hi]
+    leaf_lo = np.zeros((n, 3)); leaf_hi = np.zeros((n, 3))
+    node_lo = np.zeros((len(nodes), 3)); node_hi = np.zeros((len(nodes), 3))
+    height = np.zeros(len(nodes), int)
+    parent = np.zeros(len(nodes), int)
+    for c in range(len(nodes)):
+        for side in (0, 1):
+            k = ch[c, side]
+            if k < 0:
+                leaf_lo[~k], leaf_hi[~k] = box[c, side, :3], box[c, side, 3:]
+            else:
+                parent[k] = c
+    # bottom-up: children have larger depth; process nodes in order of decreasing depth
+    depth = np.zeros(len(nodes), int)
+    todo = [0]
+    topo = []
+    while todo:
+        c = todo.pop()
+        topo.append(c)
+        for side in (0, 1):
+            k = ch[c, side]
+            if k >= 0:
+                depth[k] = depth[c] + 1
+                todo.append(k)
+    assert len(topo) == len(nodes)
+    for c in reversed(topo):
+        lo = np.minimum(box[c, 0, :3], box[c, 1, :3]); hi = np.maximum(box[c, 0, 3:], box[c, 1, 3:])
+        node_lo[c], node_hi[c] = lo, hi
+        hc = 0
+        for side in (0, 1):
+            k = ch[c, side]
+            if k >= 0:
+                finite = np.isfinite(node_lo[k]) & np.isfinite(node_hi[k])
+                assert np.all((box[c, side, :3] <= node_lo[k]) | ~finite) and np.all((box[c, side, 3:] >= node_hi[k]) | ~finite)
+                hc = max(hc, height[k])
+        height[c] = hc + 1
+    assert height[0] <= max_height
+    # coverage of the triangles by their leaves
+    rng = np.random.default_rng(seed)
+    bary = np.concatenate([np.eye(3), rng.dirichlet((1, 1, 1), 13)])            # [16, 3]
+    tri_of_leaf = np.asarray(order, int)
+    pts = np.einsum("sb,nbc->nsc", bary, pos_all[tri_of_leaf].astype(np.float64))  # same 16 points for every piece of a triangle
+    inside = np.all((pts >= leaf_lo[:, None, :]) & (pts <= leaf_hi[:, None, :]), axis=2)  # [leaf, sample]
+    covered = np.zeros((tri_count, len(bary)), bool)
+    np.logical_or.at(covered, tri_of_leaf - tri_offset, inside)
+    ok = np.all(np.isfinite(pos_all[tri_offset:tri_offset + tri_count].reshape(tri_count, -1)), axis=1)
+    assert np.all(covered[ok]), f"{int((~covered[ok]).sum())} sample points outside every leaf of their triangle"
+    return int(height[0])

@@ -100,33 +100,22 @@ def test_lbvh_structure_on_gpu(gpu_ctx, host_scene):
         for mi in range(d.n_meshes):
             m = d.meshes[mi]
             nodes, order = ctx.copy_bvh(mi)
-            assert len(nodes) == m.tri_count - 1
-            assert sorted(order) == list(range(m.tri_offset, m.tri_offset + m.tri_count))
-            ch = nodes[:, 12:14].copy().view(np.int32)
-            leaves = np.concatenate([~ch[ch < 0]])
-            assert sorted(leaves) == list(range(m.tri_count))
-            internal = ch[ch >= 0]
-            assert sorted(internal) == list(range(1, len(nodes)))
-            # leaf boxes enclose their triangle
-            for c in range(0, len(nodes), 97):
-                for side in (0, 1):
-                    k = ch[c, side]
-                    if k < 0:
-                        p = pos_all[order[~k]]
-                        lo, hi = nodes[c, 6 * side:6 * side + 3], nodes[c, 6 * side + 3:6 * side + 6]
-                        assert np.all(lo <= p.min(0)) and np.all(hi >= p.max(0))
+            parity.check_lbvh(nodes, order, pos_all, m.tri_offset, m.tri_count)
         assert 0 < ctx.counters().bvh_max_depth <= 48
 
 
 def test_cpu_twin_and_gpu_agree_on_the_lbvh(gpu_ctx, host_scene):
     """The serial host build and the GPU build produce the same tree (same keys, same sort, same fit)."""
     import twin_lib as T
-    d = host_scene("teapot").flatten().contents
-    tw = T.Twin(host_scene("teapot"))
-    n0, o0 = tw.copy_bvh(0, d.meshes[0].tri_count)
-    n1, o1 = gpu_ctx("teapot").copy_bvh(0)
-    assert np.array_equal(o0, o1)
-    assert np.array_equal(n0.view(np.uint32), n1.view(np.uint32))
+    for preset in ("teapot", "shells"):  # shells: with triangles cut into pieces
+        d = host_scene(preset).flatten().contents
+        tw = T.Twin(host_scene(preset))
+        ctx = gpu_ctx(preset)
+        for mi in range(d.n_meshes):
+            n0, o0 = tw.copy_bvh(mi)
+            n1, o1 = ctx.copy_bvh(mi)
+            assert np.array_equal(o0, o1)
+            assert np.array_equal(n0.view(np.uint32), n1.view(np.uint32))
 
 
 def test_sharded_render_reassembles_bitwise(gpu_ctx):

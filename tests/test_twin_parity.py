@@ -66,36 +66,19 @@ def test_frames_match_oracle(preset, mode, grid, twin, oracle_scene):
 
 
 def test_lbvh_structure(twin, host_scene):
-    """Every triangle is a leaf exactly once, child boxes enclose their subtrees, height fits the stack."""
+    """Every triangle is behind a leaf (a large one behind several, one per piece), the leaves of a triangle
+    cover it, child boxes enclose their subtrees, the height fits the stack; cutting shortens the shells' tree."""
     for preset in ("teapot", "shells"):
         d = host_scene(preset).flatten().contents
         tw = twin(preset)
         pos_all = np.ctypeslib.as_array(d.tri_pos, shape=(d.n_triangles * 9,)).reshape(-1, 3, 3)
         for mi in range(d.n_meshes):
             m = d.meshes[mi]
-            nodes, order = tw.copy_bvh(mi, m.tri_count)
-            assert sorted(order) == list(range(m.tri_offset, m.tri_offset + m.tri_count))
-            children = nodes[:, 12:14].copy().view(np.int32)
-            seen_leaf, seen_node = np.zeros(m.tri_count, int), np.zeros(len(nodes), int)
-            lo = np.full((len(nodes), 3), np.inf); hi = np.full((len(nodes), 3), -np.inf)
-
-            def bounds(c):
-                if c < 0:
-                    seen_leaf[~c] += 1
-                    p = pos_all[order[~c]]
-                    return p.min(0), p.max(0), 0
-                seen_node[c] += 1
-                l0, h0, d0 = bounds(children[c, 0])
-                l1, h1, d1 = bounds(children[c, 1])
-                assert np.all(nodes[c, 0:3] <= l0) and np.all(nodes[c, 3:6] >= h0)
-                assert np.all(nodes[c, 6:9] <= l1) and np.all(nodes[c, 9:12] >= h1)
-                return np.minimum(l0, l1), np.maximum(h0, h1), 1 + max(d0, d1)
-
-            import sys
-            sys.setrecursionlimit(10000)
-            _, _, height = bounds(0)
-            assert np.all(seen_leaf == 1) and np.all(seen_node == 1)
-            assert height <= 48
+            nodes, order = tw.copy_bvh(mi)
+            height = parity.check_lbvh(nodes, order, pos_all, m.tri_offset, m.tri_count)
+            assert len(order) <= 4 * m.tri_count + 64
+            if preset == "teapot":
+                assert len(order) == m.tri_count  # no triangle of it is large enough to cut
         assert tw.height <= 48
 
 

@@ -41,6 +41,7 @@ def lib():
         L.twin_intersect_object.argtypes = [vp, C.c_int, C.c_int64, vp, vp, C.c_int, vp]
         L.twin_render.argtypes = [vp, C.POINTER(rt.RenderParams), C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp]
         L.twin_copy_bvh.argtypes = [vp, C.c_int, vp, vp]
+        L.twin_ref_count.argtypes = [vp, C.c_int]
         _lib = L
     return _lib
 
@@ -93,7 +94,9 @@ class Twin:
         self.L.twin_render(self.h, C.byref(p), x0, y0, x1, y1, _p(rgb), _p(rgb8), _p(counters))
         return rgb, rgb8, counters
 
-    def copy_bvh(self, mesh, ntri):
+    def copy_bvh(self, mesh, ntri=None):
+        """nodes and the triangle behind every leaf (a triangle cut into pieces appears once per piece)"""
+        ntri = self.L.twin_ref_count(self.h, mesh)
         nodes = np.zeros((max(ntri - 1, 1), 16), np.float32)
         order = np.zeros(max(ntri, 1), np.int32)
         nn = self.L.twin_copy_bvh(self.h, mesh, _p(nodes), _p(order))
