@@ -97,37 +97,20 @@ def main():
     ctx = rt.Context(local_rank)
     scene = rt.HostScene(preset)
     ctx.upload(scene)
-    stream = torch.cuda.Stream(device=local_rank)  # kernels, collectives and events share this stream
-    torch.cuda.set_stream(stream)
-    ctx.set_stream(stream.cuda_stream)
 
+    # render on one stream, exchange + untile on another, two buffers each: frame k's all-gather overlaps
+    # frame k+1's rendering (ray_tracer_amd/frames.py)
+    from ray_tracer_amd.frames import FramePipeline
+    ff = args.float_frame
+    pipe = FramePipeline(ctx, width, height, rank=rank, world=world, device=local_rank, float_frame=ff)
+    torch.cuda.set_stream(pipe.render_stream)
     p = ctx.params(width, height, mode=mode, grid_m=grid_m, max_depth=max_depth, accel=accel,
                    rank=rank, world_size=world)
-    per_rank, total_tiles = ctx.shard_tiles(p)
-    shard_elems = per_rank * rt.TILE * rt.TILE * 3
-    dev = torch.device("cuda", local_rank)
-    ff = args.float_frame
-    shard = torch.zeros(shard_elems, dtype=torch.float32, device=dev) if ff else None
-    shard8 = torch.zeros(shard_elems, dtype=torch.uint8, device=dev)
-    gathered = (torch.zeros(world * shard_elems, dtype=torch.float32, device=dev) if world > 1 else shard) if ff else None
-    gathered8 = torch.zeros(world * shard_elems, dtype=torch.uint8, device=dev) if world > 1 else shard8
-    frame = torch.zeros(height * width * 3, dtype=torch.float32, device=dev) if ff else None
-    frame8 = torch.zeros(height * width * 3, dtype=torch.uint8, device=dev)
-
-    def ptr(t):
-        return t.data_ptr() if t is not None else None
+    total_tiles = pipe.total_tiles
+    dev = pipe.dev
 
     def step(events=None):
-        if events is not None:
-            events[0].record(stream)
-        ctx.render_shard_device(p, ptr(shard), ptr(shard8))
-        if events is not None:
-            events[1].record(stream)
-        if world > 1:
-            if ff:
-                dist.all_gather_into_tensor(gathered, shard)
-            dist.all_gather_into_tensor(gathered8, shard8)
-        ctx.untile_device(p, ptr(gathered), ptr(frame), ptr(gathered8), ptr(frame8))
+        pipe.submit(p, events)
 
     def barrier():
         if world > 1:
@@ -161,7 +144,7 @@ def main():
     ctx.reset_counters()
     pc = ctx.params(width, height, mode=mode, grid_m=grid_m, max_depth=max_depth, accel=accel,
                     rank=rank, world_size=world, count_work=True)
-    ctx.render_shard_device(pc, ptr(shard), ptr(shard8))
+    pipe.submit(pc)
     torch.cuda.synchronize()
     cw = ctx.counters()
     flops_local = (cw.tri_tests * FLOPS["tri_tests"] + cw.box_tests * FLOPS["box_tests"] +
@@ -202,6 +185,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(preset, width, height, mode, grid_m, max_depth)
         print(json.dumps(out), flush=True)
+    pipe.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -224,6 +224,13 @@ int rt_render_shard_device(rt_ctx *ctx, const rt_render_params *p, float *d_rgb_
  * them) into row-major frames on the device.  Either pair may be NULL. */
 int rt_untile_device(rt_ctx *ctx, const rt_render_params *p, const float *d_rgb_shards,
                      float *d_rgb_frame, const uint8_t *d_rgb8_shards, uint8_t *d_rgb8_frame);
+/* The same on a stream the caller names (hipStream_t; NULL = the default stream) instead of the
+ * context's: lets the exchange + untile of one frame run beside the rendering of the next.  The
+ * caller orders it after the render / gather that produced the shards (events).  No counterpart in
+ * the reference. */
+int rt_untile_device_on(rt_ctx *ctx, void *hip_stream, const rt_render_params *p,
+                        const float *d_rgb_shards, float *d_rgb_frame,
+                        const uint8_t *d_rgb8_shards, uint8_t *d_rgb8_frame);
 int rt_sync(rt_ctx *ctx);
 /* The HIP stream (hipStream_t) the context launches on, for event timing by the caller. */
 void *rt_stream(rt_ctx *ctx);

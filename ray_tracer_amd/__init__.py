@@ -124,7 +124,7 @@ HIT_DTYPE = np.dtype([("hit", "i4"), ("object", "i4"), ("frag", "i4"), ("sub", "
 ABI_SYMBOLS = ["rt_context_create", "rt_context_destroy", "rt_last_error", "rt_scene_upload", "rt_scene_update",
                "rt_build_accel", "rt_render", "rt_shard_tiles", "rt_render_shard_device",
                "rt_untile_device", "rt_sync", "rt_stream", "rt_set_stream", "rt_trace_rays", "rt_intersect_object",
-               "rt_get_counters", "rt_reset_counters", "rt_debug_copy_bvh"]
+               "rt_get_counters", "rt_reset_counters", "rt_debug_copy_bvh", "rt_untile_device_on"]
 
 _amd = None
 _host = None
@@ -157,6 +157,7 @@ def amd():
         L.rt_shard_tiles.argtypes = [C.POINTER(RenderParams), C.POINTER(i32), C.POINTER(i32)]
         L.rt_render_shard_device.argtypes = [vp, C.POINTER(RenderParams), vp, vp]
         L.rt_untile_device.argtypes = [vp, C.POINTER(RenderParams), vp, vp, vp, vp]
+        L.rt_untile_device_on.argtypes = [vp, vp, C.POINTER(RenderParams), vp, vp, vp, vp]
         L.rt_sync.argtypes = [vp]
         L.rt_stream.argtypes = [vp]
         L.rt_stream.restype = vp
@@ -409,6 +410,10 @@ class Context:
     def untile_device(self, p, d_rgb_shards, d_rgb_frame, d_rgb8_shards, d_rgb8_frame):
         self._check(self.L.rt_untile_device(self.h, C.byref(p), d_rgb_shards, d_rgb_frame,
                                             d_rgb8_shards, d_rgb8_frame), "rt_untile_device")
+
+    def untile_device_on(self, hip_stream, p, d_rgb_shards, d_rgb_frame, d_rgb8_shards, d_rgb8_frame):
+        self._check(self.L.rt_untile_device_on(self.h, hip_stream, C.byref(p), d_rgb_shards, d_rgb_frame,
+                                               d_rgb8_shards, d_rgb8_frame), "rt_untile_device_on")
 
     def sync(self):
         self._check(self.L.rt_sync(self.h), "rt_sync")

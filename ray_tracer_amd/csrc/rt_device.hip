@@ -791,8 +791,8 @@ extern "C" int rt_render_shard_device(rt_ctx *ctx, const rt_render_params *p, fl
     return RT_OK;
 }
 
-extern "C" int rt_untile_device(rt_ctx *ctx, const rt_render_params *p, const float *d_rgb_shards, float *d_rgb_frame,
-                                const uint8_t *d_rgb8_shards, uint8_t *d_rgb8_frame) {
+static int untile_on(rt_ctx *ctx, hipStream_t stream, const rt_render_params *p, const float *d_rgb_shards, float *d_rgb_frame,
+                     const uint8_t *d_rgb8_shards, uint8_t *d_rgb8_frame) {
     if (!ctx) return RT_ERR_INVALID;
     int rc = check_params(ctx, p);
     if (rc) return rc;
@@ -803,13 +803,23 @@ extern "C" int rt_untile_device(rt_ctx *ctx, const rt_render_params *p, const fl
     size_t elems = (size_t)p->world_size * per_rank * RT_TILE_W * RT_TILE_H;
     dim3 blk(256), grd((unsigned)((elems + 255) / 256));
     if (d_rgb_shards && d_rgb_frame)
-        hipLaunchKernelGGL(k_untile<float>, grd, blk, 0, ctx->stream, d_rgb_shards, d_rgb_frame, p->width, p->height, tiles_x, total,
+        hipLaunchKernelGGL(k_untile<float>, grd, blk, 0, stream, d_rgb_shards, d_rgb_frame, p->width, p->height, tiles_x, total,
                            per_rank, p->world_size, 0, p->world_size);
     if (d_rgb8_shards && d_rgb8_frame)
-        hipLaunchKernelGGL(k_untile<uint8_t>, grd, blk, 0, ctx->stream, d_rgb8_shards, d_rgb8_frame, p->width, p->height, tiles_x,
+        hipLaunchKernelGGL(k_untile<uint8_t>, grd, blk, 0, stream, d_rgb8_shards, d_rgb8_frame, p->width, p->height, tiles_x,
                            total, per_rank, p->world_size, 0, p->world_size);
     RT_HIP(hipGetLastError());
     return RT_OK;
+}
+
+extern "C" int rt_untile_device(rt_ctx *ctx, const rt_render_params *p, const float *d_rgb_shards, float *d_rgb_frame,
+                                const uint8_t *d_rgb8_shards, uint8_t *d_rgb8_frame) {
+    return untile_on(ctx, ctx ? ctx->stream : nullptr, p, d_rgb_shards, d_rgb_frame, d_rgb8_shards, d_rgb8_frame);
+}
+
+extern "C" int rt_untile_device_on(rt_ctx *ctx, void *hip_stream, const rt_render_params *p, const float *d_rgb_shards,
+                                   float *d_rgb_frame, const uint8_t *d_rgb8_shards, uint8_t *d_rgb8_frame) {
+    return untile_on(ctx, static_cast<hipStream_t>(hip_stream), p, d_rgb_shards, d_rgb_frame, d_rgb8_shards, d_rgb8_frame);
 }
 
 extern "C" int rt_render(rt_ctx *ctx, const rt_render_params *p, float *rgb_linear, uint8_t *rgb8) {

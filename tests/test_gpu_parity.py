@@ -330,3 +330,42 @@ def test_tap_splitting_kernel_is_bit_identical(preset, mode, grid, host_scene, m
     assert np.array_equal(split, plain, equal_nan=True) and np.array_equal(split8, plain8)
     assert split_rays == plain_rays
     assert plain8.std() > 5  # a picture, not a constant
+
+
+@pytest.mark.parametrize("collective", [False, True])
+def test_frame_pipeline_overlapped_frames_equal_serial(gpu_ctx, collective):
+    """Frames queued back to back through the two-stream pipeline (render of frame k+1 overlapping the
+    exchange and untile of frame k, two shard and frame buffers) equal the frames rendered one by one.
+    Every frame has another camera, so a buffer that is reused too early shows.  collective=True sends
+    the shards through a real (single-rank) RCCL all-gather."""
+    import torch
+    import torch.distributed as dist
+    from ray_tracer_amd.frames import FramePipeline
+    ctx = gpu_ctx("teapot")
+    w, h = 400, 240
+    fovs = [90.0, 60.0, 75.0, 50.0, 100.0, 40.0, 85.0]
+    expect = [ctx.render(w, h, fov=f, mode=rt.MODE_GRID, grid_m=2) for f in fovs]
+    own_group = False
+    if collective and not dist.is_initialized():
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{29600 + os.getpid() % 1000}", rank=0,
+                                world_size=1, device_id=torch.device("cuda", 0))
+        own_group = True
+    try:
+        pipe = FramePipeline(ctx, w, h, float_frame=True, force_collective=collective)
+        got, pending = [], None
+        for f in fovs + [None]:
+            nxt = pipe.submit(ctx.params(w, h, fov=f, mode=rt.MODE_GRID, grid_m=2)) if f is not None else None
+            if pending is not None:  # collect frame k while frame k+1 is in flight
+                slot, done = pending
+                done.synchronize()
+                got.append((pipe.frame[slot].cpu().numpy().reshape(h, w, 3).copy(),
+                            pipe.frame8[slot].cpu().numpy().reshape(h, w, 3).copy()))
+            pending = nxt
+        pipe.close()
+    finally:
+        if own_group:
+            dist.destroy_process_group()
+    assert len(got) == len(fovs)
+    for (e, e8), (g, g8) in zip(expect, got):
+        assert np.array_equal(e8, g8)
+        assert np.array_equal(e, g, equal_nan=True)
