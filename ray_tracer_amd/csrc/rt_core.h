@@ -29,7 +29,7 @@ namespace rtc {
 
 constexpr float kEps = 0.0001f;     // EPS, main.cpp:23
 constexpr float kMinDist = 0.01f;   // find_closest_hit threshold, main.cpp:705
-constexpr int kStackDepth = 48;     // LBVH traversal stack entries per wave (a tree may be this high)
+constexpr int kStackDepth = 64;     // LBVH traversal stack entries per wave: a tree over unique 64-bit keys is never higher
 constexpr double kPi = 3.14159265358979323846;
 
 // Scene features a kernel instantiation supports.  A scene is rendered by the leanest

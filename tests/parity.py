@@ -123,7 +123,7 @@ def check_rgb8(ref, got, what="", frac=0.999):
     return diff
 
 
-def check_lbvh(nodes, order, pos_all, tri_offset, tri_count, max_height=48, seed=0):
+def check_lbvh(nodes, order, pos_all, tri_offset, tri_count, max_height=64, seed=0):
     """Structure of one mesh's LBVH.  `order[k]` is the triangle behind leaf k; a large triangle is cut into
     pieces and is then behind several leaves, each with the box of its piece.
     Checked: every triangle is behind at least one leaf and nothing else is; every leaf and every internal
@@ -187,3 +187,39 @@ def check_lbvh(nodes, order, pos_all, tri_offset, tri_count, max_height=48, seed
     ok = np.all(np.isfinite(pos_all[tri_offset:tri_offset + tri_count].reshape(tri_count, -1)), axis=1)
     assert np.all(covered[ok]), f"{int((~covered[ok]).sum())} sample points outside every leaf of their triangle"
     return int(height[0])
+
+
+def deep_tree_scene(n_small=3000, seed=5):
+    """A mesh whose LBVH is tall: triangles whose centroids halve their distance to one corner of the bounds
+    (a chain through the Morton code's bit levels) and thousands of tiny triangles inside the last cell
+    (equal Morton codes: a subtree on the index bits alone).  All face the camera at the origin."""
+    import ray_tracer_amd as rt
+    rng = np.random.default_rng(seed)
+    tris = []
+
+    def tri(c, s):
+        c = np.asarray(c, np.float64)
+        return np.concatenate([c + (-s, -s, 0), c + (0, s, 0), c + (s, -s, 0)])  # normal -z: faces the camera
+
+    corner = np.array([-4.0, -3.0, 6.0])
+    cell = 8.0 / 1024  # the sort key has 10 bits per axis over the mesh bounds (an 8-unit cube here)
+    tris.append(tri(corner, 1e-3))
+    tris.append(tri(corner + 8.0, 1e-3))  # fixes the bounds
+    for axis in range(3):
+        for bit in range(10):  # one triangle per single-bit Morton code: a chain of 30 levels
+            c = np.full(3, 0.25 * cell)
+            c[axis] += cell * (1 << bit)
+            tris.append(tri(corner + c, 0.1 * cell))
+    for _ in range(n_small):
+        tris.append(tri(corner + rng.uniform(0.1, 0.9, 3) * cell, 1e-3 * cell * 50))
+    pos = np.asarray(tris, np.float32)
+    nrm = np.tile(np.array([0, 0, -1], np.float32), (len(pos), 3))
+    hs = rt.HostScene()
+    hs.add_mesh_tris(pos, nrm, rt.mat_identity(), rt.Material(diffuse=(0.8, 0.5, 0.2)), boxed=False)
+    hs.add_plane((0, 0, 20), (0, 0, -1), rt.Material(diffuse=(0.3, 0.3, 0.3)))
+    hs.add_light((0, 8, 0), 1.0)
+    # rays at the chain and, densely, at the cluster of tiny triangles
+    targets = np.concatenate([pos.reshape(-1, 3, 3).mean(1)[:32].astype(np.float64),
+                              corner + rng.uniform(-0.25, 1.25, (4000, 3)) * cell])
+    d = targets / np.linalg.norm(targets, axis=1, keepdims=True)
+    return hs, np.zeros_like(d, dtype=np.float32), d.astype(np.float32)

@@ -101,7 +101,7 @@ def test_lbvh_structure_on_gpu(gpu_ctx, host_scene):
             m = d.meshes[mi]
             nodes, order = ctx.copy_bvh(mi)
             parity.check_lbvh(nodes, order, pos_all, m.tri_offset, m.tri_count)
-        assert 0 < ctx.counters().bvh_max_depth <= 48
+        assert 0 < ctx.counters().bvh_max_depth <= 64
 
 
 def test_cpu_twin_and_gpu_agree_on_the_lbvh(gpu_ctx, host_scene):
@@ -369,3 +369,23 @@ def test_frame_pipeline_overlapped_frames_equal_serial(gpu_ctx, collective):
     for (e, e8), (g, g8) in zip(expect, got):
         assert np.array_equal(e8, g8)
         assert np.array_equal(e, g, equal_nan=True)
+
+
+def test_tall_tree_equals_brute_force_on_gpu():
+    """The tall-tree mesh (Morton chain + thousands of equal codes): packet traversal and linear scan give the
+    same records and radiance, and both match the CPU twin."""
+    import twin_lib as T
+    hs, o, d = parity.deep_tree_scene()
+    ctx = rt.Context(0)
+    try:
+        ctx.upload(hs)
+        assert 30 <= ctx.counters().bvh_max_depth <= 64
+        a, ra = ctx.trace_rays(o, d, 4, rt.ACCEL_LBVH)
+        b, rb = ctx.trace_rays(o, d, 4, rt.ACCEL_BRUTE)
+    finally:
+        ctx.close()
+    assert a.tobytes() == b.tobytes() and np.array_equal(ra, rb, equal_nan=True)
+    tw = T.Twin(hs)
+    c, rc = tw.trace_rays(o, d, 4, rt.ACCEL_LBVH)
+    parity.check_hits(c, a, "tall tree")
+    parity.check_radiance(rc, ra, "tall tree")
