@@ -106,14 +106,14 @@ class Counters(C.Structure):
                 ("gate_tests", C.c_uint64), ("quadric_tests", C.c_uint64),
                 ("plane_tests", C.c_uint64), ("shade_evals", C.c_uint64), ("tex_fetches", C.c_uint64),
                 ("last_trace_ms", C.c_float), ("last_build_ms", C.c_float),
-                ("bvh_max_depth", C.c_int32), ("reserved", C.c_int32)]
+                ("bvh_max_depth", C.c_int32), ("render_variant", C.c_int32)]
 
     @property
     def rays(self):
         return self.rays_primary + self.rays_shadow + self.rays_secondary
 
     def as_dict(self):
-        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+        return {k: getattr(self, k) for k, _ in self._fields_ }
 
 
 HIT_DTYPE = np.dtype([("hit", "i4"), ("object", "i4"), ("frag", "i4"), ("sub", "i4"),

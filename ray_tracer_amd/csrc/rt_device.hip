@@ -226,7 +226,7 @@ struct TapSlice {  // a trace_loop source: taps [k, k_end) of one pixel
 };
 
 template <int F, bool COUNT>
-__global__ __launch_bounds__(kBlock, 4) void k_render_split(DevScene S, RenderArgs a, float *rgb_tiles,
+__global__ __launch_bounds__(kBlock, render_waves(F, COUNT)) void k_render_split(DevScene S, RenderArgs a, float *rgb_tiles,
                                                                                  uint8_t *rgb8_tiles, unsigned long long *counters) {
     RT_WAVE_STACK(stk, F);
     __shared__ float tap_lds[kRoundTaps * 3 * 64];
@@ -355,6 +355,18 @@ struct rt_ctx {
     int bvh_max_depth = 0;
     int split_min_taps = 32;  // taps per pixel from which k_render_split is used for scenes with meshes
     bool split_forced = false;  // RT_SPLIT_MIN_TAPS (tests, tuning) sets the threshold for every scene
+    int n_cus = 256;            // compute units of the device
+    // Which of the two render kernels (0: k_render, 1: k_render_split; same pixels bit for bit) is faster for
+    // the current frame parameters: each is timed once, on the first two launches with these parameters.
+    struct Tune {
+        int32_t key[11] = {0};
+        bool valid = false;
+        hipEvent_t ev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+        bool recorded[2] = {false, false}, have[2] = {false, false};
+        float ms[2] = {0, 0};
+        int choice = -1;
+    } tune;
+    int last_variant = 0;
 };
 
 #define RT_HIP(call)                                                                             \
@@ -407,6 +419,10 @@ extern "C" int rt_context_create(int device, rt_ctx **out) {
         return RT_ERR_HIP;
     }
     ctx->stream = ctx->own_stream;
+    for (int v = 0; v < 2; v++)
+        for (int k = 0; k < 2; k++)
+            if (hipEventCreate(&ctx->tune.ev[v][k]) != hipSuccess) { delete ctx; return RT_ERR_HIP; }
+    if (hipDeviceGetAttribute(&ctx->n_cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || ctx->n_cus <= 0) ctx->n_cus = 256;
     if (const char *e = std::getenv("RT_SPLIT_MIN_TAPS")) { ctx->split_min_taps = std::atoi(e); ctx->split_forced = true; }
     void *c = nullptr;
     if (hipMalloc(&c, (size_t)kCounterStripes * kCounterStride * sizeof(unsigned long long)) != hipSuccess ||
@@ -427,6 +443,8 @@ extern "C" int rt_context_destroy(rt_ctx *ctx) {
     (void)hipFree(ctx->d_counters);
     (void)hipEventDestroy(ctx->ev0);
     (void)hipEventDestroy(ctx->ev1);
+    for (int v = 0; v < 2; v++)
+        for (int k = 0; k < 2; k++) (void)hipEventDestroy(ctx->tune.ev[v][k]);
     (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return RT_OK;
@@ -567,6 +585,7 @@ extern "C" int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *sc) {
     RT_HIP(hipStreamSynchronize(ctx->stream));  // the caller's arrays may go away after return
     ctx->features = scene_features(sc);
     ctx->uploaded = true;
+    ctx->tune.valid = false;  // another scene: time the render kernels again
     ctx->built = false;
     ctx->n_textures = sc->n_textures;
     ctx->n_materials = sc->n_materials;
@@ -774,7 +793,40 @@ extern "C" int rt_render_shard_device(rt_ctx *ctx, const rt_render_params *p, fl
     // variant that spreads a pixel's taps over the waves of a block
     typedef void (*render_fn)(DevScene, RenderArgs, float *, uint8_t *, unsigned long long *);
     // (meshes are what concentrates a frame's cost in few pixels; without them the split only adds its barriers)
-    const bool split = taps_of(p->mode, p->grid_m) >= ctx->split_min_taps && ((ctx->features & F_MESH) || ctx->split_forced);
+    // A block of k_render runs all taps of its pixels one after the other, and a tile on a mesh takes many times
+    // as long as the average tile.  With many taps, or with so few tiles per launch that the launch is no longer
+    // than a few such blocks (one rank's share of a frame on several GPUs), that one block decides the frame time
+    // and k_render_split, whose blocks are a quarter as long, is faster in spite of its barriers.  Which one wins
+    // depends on the scene, so both are timed once (first two launches with these parameters; they write the
+    // same pixels) and the faster one is kept; until the timings are in, the rule of thumb below decides.
+    const int taps = taps_of(p->mode, p->grid_m);
+    const bool few_tiles = taps >= 2 * kRoundTaps && local_tiles < 12 * 5 * ctx->n_cus;  // under 12 rounds of resident blocks
+    bool split = ctx->split_forced ? taps >= ctx->split_min_taps
+                                   : (ctx->features & F_MESH) && (taps >= ctx->split_min_taps || few_tiles);
+    int measure = -1;
+    if (!ctx->split_forced && !p->count_work && taps >= 4 && (ctx->features & F_MESH)) {
+        rt_ctx::Tune &t = ctx->tune;
+        int32_t fov_bits;
+        std::memcpy(&fov_bits, &p->fov, sizeof fov_bits);
+        const int32_t key[11] = {p->width, p->height, p->mode, p->grid_m, p->max_depth, p->accel, p->rank, p->world_size,
+                                 fov_bits, ctx->features, 1};
+        if (!t.valid || std::memcmp(key, t.key, sizeof key) != 0) {
+            std::memcpy(t.key, key, sizeof key);
+            t.valid = true;
+            t.recorded[0] = t.recorded[1] = t.have[0] = t.have[1] = false;
+            t.choice = -1;
+        }
+        for (int v = 0; v < 2 && t.choice < 0; v++)
+            if (t.recorded[v] && !t.have[v] && hipEventQuery(t.ev[v][1]) == hipSuccess &&
+                hipEventElapsedTime(&t.ms[v], t.ev[v][0], t.ev[v][1]) == hipSuccess)
+                t.have[v] = true;
+        (void)hipGetLastError();  // hipErrorNotReady from the query is not an error of this call
+        if (t.choice < 0 && t.have[0] && t.have[1]) t.choice = t.ms[1] < 0.95f * t.ms[0] ? 1 : 0;  // the first launch ran cold
+        if (t.choice >= 0) split = t.choice == 1;
+        else if (!t.recorded[0]) { split = false; measure = 0; }
+        else if (!t.recorded[1]) { split = true; measure = 1; }
+    }
+    ctx->last_variant = split ? 1 : 0;
     render_fn kernel = split ? k_render_split<F_ALL, false> : k_render<F_ALL, false>;
     int f = ctx->features;
 #define RT_PICK(FEATURES) (split ? (render_fn)k_render_split<FEATURES, false> : (render_fn)k_render<FEATURES, false>)
@@ -784,9 +836,14 @@ extern "C" int rt_render_shard_device(rt_ctx *ctx, const rt_render_params *p, fl
     else if ((f & ~(F_QUADRIC | F_SECONDARY)) == 0) kernel = RT_PICK(F_QUADRIC | F_SECONDARY);
     else if ((f & ~(F_MESH | F_TEXTURE | F_SECONDARY)) == 0) kernel = RT_PICK(F_MESH | F_TEXTURE | F_SECONDARY);
 #undef RT_PICK
+    if (measure >= 0) RT_HIP(hipEventRecord(ctx->tune.ev[measure][0], ctx->stream));
     hipLaunchKernelGGL(kernel, dim3(split ? 4 * local_tiles : local_tiles), dim3(kBlock), 0, ctx->stream, ctx->S, a, d_rgb_tiles,
                        d_rgb8_tiles, ctx->d_counters);
     RT_HIP(hipGetLastError());
+    if (measure >= 0) {
+        RT_HIP(hipEventRecord(ctx->tune.ev[measure][1], ctx->stream));
+        ctx->tune.recorded[measure] = true;
+    }
     RT_HIP(hipEventRecord(ctx->ev1, ctx->stream));
     return RT_OK;
 }
@@ -947,6 +1004,7 @@ extern "C" int rt_get_counters(rt_ctx *ctx, rt_counters *out) {
     out->last_trace_ms = ctx->last_trace_ms;
     out->last_build_ms = ctx->last_build_ms;
     out->bvh_max_depth = ctx->bvh_max_depth;
+    out->render_variant = ctx->last_variant;
     return RT_OK;
 }
 

@@ -389,3 +389,19 @@ def test_tall_tree_equals_brute_force_on_gpu():
     c, rc = tw.trace_rays(o, d, 4, rt.ACCEL_LBVH)
     parity.check_hits(c, a, "tall tree")
     parity.check_radiance(rc, ra, "tall tree")
+
+
+def test_render_kernel_choice_by_timing_keeps_the_pixels(gpu_ctx):
+    """With new frame parameters the first launch runs the one-lane-per-pixel kernel, the second the kernel that
+    spreads a pixel's taps over a block's waves, and from the third on the one that was faster: three frames,
+    two kernels, the same bytes."""
+    if os.environ.get("RT_SPLIT_MIN_TAPS"):
+        pytest.skip("the environment fixes the kernel choice")
+    ctx = gpu_ctx("teapot")
+    frames, variants = [], []
+    for _ in range(4):
+        frames.append(ctx.render(333, 177, fov=77.0, mode=rt.MODE_GRID, grid_m=3))
+        variants.append(ctx.counters().render_variant)
+    assert variants[:2] == [0, 1] and variants[2] in (0, 1) and variants[3] == variants[2]
+    for rgb, rgb8 in frames[1:]:
+        assert np.array_equal(rgb8, frames[0][1]) and np.array_equal(rgb, frames[0][0], equal_nan=True)
