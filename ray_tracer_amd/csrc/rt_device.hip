@@ -800,7 +800,7 @@ extern "C" int rt_render_shard_device(rt_ctx *ctx, const rt_render_params *p, fl
     // depends on the scene, so both are timed once (first two launches with these parameters; they write the
     // same pixels) and the faster one is kept; until the timings are in, the rule of thumb below decides.
     const int taps = taps_of(p->mode, p->grid_m);
-    const bool few_tiles = taps >= 2 * kRoundTaps && local_tiles < 12 * 5 * ctx->n_cus;  // under 12 rounds of resident blocks
+    const bool few_tiles = taps >= 2 * kRoundTaps && local_tiles < 16 * 5 * ctx->n_cus;  // under 16 rounds of resident blocks
     bool split = ctx->split_forced ? taps >= ctx->split_min_taps
                                    : (ctx->features & F_MESH) && (taps >= ctx->split_min_taps || few_tiles);
     int measure = -1;

@@ -59,6 +59,8 @@ class FramePipeline:
         once the event has completed, and stays valid until the second submit after this one.
         timing: optional pair of events recorded around the render kernel on the render stream."""
         b = self.count & 1
+        if self.count >= 2:
+            self.done[b].synchronize()  # at most two frames in flight: the host does not run ahead of the GPU without bound
         self.count += 1
         ctx, R, X = self.ctx, self.render_stream, self.exchange_stream
         ptr = self._ptr
