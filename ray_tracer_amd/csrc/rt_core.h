@@ -822,26 +822,29 @@ RT_HD bool closer(float dist, int32_t idx, const Closest &best) {
     return (dist > kMinDist) & ((dist < best.distance) | ((dist == best.distance) & (idx < best.object)));
 }
 // the common tail of both plane tests: estimate, wave-wide skip, exact quotient, acceptance
+// (`facing` and the skip test are kept as wave masks: a ballot taken directly of a comparison is the
+// comparison's own result register, while a ballot of a combined bool costs two more vector instructions)
 template <bool COUNT>
-RT_HD void plane_accept(float DdotN, float PdotN, bool facing, int32_t idx, Closest &best, Work &wk) {
+RT_HD void plane_accept(float DdotN, float PdotN, uint64_t facing, int32_t idx, Closest &best, Work &wk) {
     if (COUNT) wk.plane++;
     float est = PdotN * shade_rcp(DdotN);
-    bool maybe = facing & (est > 0.5f * kMinDist) & !(est > best.distance * 1.00001f);
-    if (wave_ballot(maybe) != 0) {
+    uint64_t maybe = facing & wave_ballot(est > 0.5f * kMinDist) & ~wave_ballot(est > best.distance * 1.00001f);
+    if (maybe != 0) {
         float t = PdotN / DdotN;
-        bool ok = facing & (t > 0) & closer(t, idx, best);
+        const bool faces = wave_mask_bit(facing), ahead = t > 0, nearer = closer(t, idx, best);
+        bool ok = faces & ahead & nearer;
         best.distance = ok ? t : best.distance; best.object = ok ? idx : best.object; best.t = ok ? t : best.t;
     }
 }
 template <bool COUNT>
-RT_HD void plane_axis_test(int32_t axis, float coord, int32_t idx, uint32_t skip, v3 ro, v3 rd, bool finite, Closest &best, Work &wk) {
+RT_HD void plane_axis_test(int32_t axis, float coord, int32_t idx, uint32_t skip, v3 ro, v3 rd, uint64_t finite, Closest &best, Work &wk) {
     if (axis == 0 || skip != 0) return;  // padding, or a plane that cannot shadow this wave's light (wave-uniform)
     // (-q) / (-dd) == q / dd bit for bit, so the sign of the normal only decides `facing`
     int a = (axis < 0 ? -axis : axis) - 1;
     float dd = a == 0 ? rd.x : a == 1 ? rd.y : rd.z;
     float oo = a == 0 ? ro.x : a == 1 ? ro.y : ro.z;
-    bool facing = finite & (axis < 0 ? dd > 0 : dd < 0);
-    plane_accept<COUNT>(dd, coord - oo, facing, idx, best, wk);
+    uint64_t ahead = wave_ballot(dd > 0), against = wave_ballot(dd < 0);
+    plane_accept<COUNT>(dd, coord - oo, finite & (axis < 0 ? ahead : against), idx, best, wk);
 }
 template <bool COUNT>
 RT_HD void plane_gen_test(const u32x16 &g, int at, uint32_t light_bit, v3 ro, v3 rd, Closest &best, Work &wk) {
@@ -850,7 +853,7 @@ RT_HD void plane_gen_test(const u32x16 &g, int at, uint32_t light_bit, v3 ro, v3
     v3 n = V3(u2f(g[at]), u2f(g[at + 1]), u2f(g[at + 2]));
     float DdotN = dot(rd, n);
     float PdotN = dot(V3(u2f(g[at + 3]), u2f(g[at + 4]), u2f(g[at + 5])) - ro, n);
-    plane_accept<COUNT>(DdotN, PdotN, DdotN < 0, idx, best, wk);
+    plane_accept<COUNT>(DdotN, PdotN, wave_ballot(DdotN < 0), idx, best, wk);
 }
 
 template <int F, bool COUNT, class Stack>
@@ -871,7 +874,8 @@ RT_HD void find_closest(const DevScene &S, v3 ro, v3 rd, int accel, int light, f
     // non-finite component they are NaN and the plane is missed, which `finite` reproduces.
     // The order of the tests is free: closer() picks the same winner in any order.
     float adx = fabsf(rd.x), ady = fabsf(rd.y), adz = fabsf(rd.z), aox = fabsf(ro.x), aoy = fabsf(ro.y), aoz = fabsf(ro.z);
-    bool finite = (adx < INFINITY) & (ady < INFINITY) & (adz < INFINITY) & (aox < INFINITY) & (aoy < INFINITY) & (aoz < INFINITY);
+    const uint64_t finite = wave_ballot(adx < INFINITY) & wave_ballot(ady < INFINITY) & wave_ballot(adz < INFINITY) &
+                            wave_ballot(aox < INFINITY) & wave_ballot(aoy < INFINITY) & wave_ballot(aoz < INFINITY);
     const bool meshes = (F & F_MESH) && S.n_meshes > 0;
     u32x16 head_next = {};
     if (meshes) head_next = load_u32x16(S.meshes);  // the first mesh head travels with the first planes
