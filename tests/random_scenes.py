@@ -1,0 +1,173 @@
+"""Seeded random scenes, built twice from one description: as a `ray_tracer_amd.HostScene` (what the GPU
+library and the CPU twin take) and as an oracle scene.  Test scaffolding.
+
+Every scene mixes the object kinds of the reference (planes with axis-aligned and general normals, spheres,
+cones, triangle meshes with and without a Box gate) under random affine transformations, with diffuse,
+specular, reflective and refractive materials, procedural textures and one to three lights.
+"""
+import ctypes as C
+
+import numpy as np
+
+import oracle_lib as O
+import ray_tracer_amd as rt
+
+
+class ScenePair:
+    def __init__(self):
+        self.host = rt.HostScene()
+        self.orc = O.Scene()
+        self._keep = []
+
+    def _omat(self, m):
+        om = O.OrcMaterial()
+        om.ambient[:] = m.ambient[:]; om.diffuse[:] = m.diffuse[:]; om.specular[:] = m.specular[:]
+        om.shininess, om.reflectiveness = m.shininess, m.reflectiveness
+        om.refractiveness, om.refractive_ratio, om.texture = m.refractiveness, m.refractive_ratio, m.texture
+        return om
+
+    def checker(self):
+        a, b = self.host.add_checker_texture(), self.orc.L.orc_add_checker_texture(self.orc.h)
+        assert a == b
+        return a
+
+    def rainbow(self):
+        a, b = self.host.add_rainbow_texture(), self.orc.L.orc_add_rainbow_texture(self.orc.h)
+        assert a == b
+        return a
+
+    def plane(self, p, n, m):
+        p, n = O.f32(p), O.f32(n)
+        om = self._omat(m)
+        a = self.host.add_plane(p, n, m)
+        b = self.orc.L.orc_add_plane(self.orc.h, p.ctypes.data, n.ctypes.data, C.byref(om))
+        assert a == b
+        return a
+
+    def sphere(self, M, m):
+        M = O.f32(M); om = self._omat(m)
+        a = self.host.add_sphere(M, m)
+        b = self.orc.L.orc_add_sphere(self.orc.h, M.ctypes.data, C.byref(om))
+        assert a == b
+        return a
+
+    def cone(self, M, m):
+        M = O.f32(M); om = self._omat(m)
+        a = self.host.add_cone(M, m)
+        b = self.orc.L.orc_add_cone(self.orc.h, M.ctypes.data, C.byref(om))
+        assert a == b
+        return a
+
+    def mesh(self, pos, nrm, M, m, boxed):
+        pos, nrm, M = O.f32(pos).reshape(-1, 9), O.f32(nrm).reshape(-1, 9), O.f32(M)
+        om = self._omat(m)
+        a = self.host.add_mesh_tris(pos, nrm, M, m, boxed=boxed)
+        b = self.orc.L.orc_add_mesh_tris(self.orc.h, len(pos), pos.ctypes.data, nrm.ctypes.data, None, M.ctypes.data,
+                                         C.byref(om), int(boxed))
+        assert a == b
+        return a
+
+    def light(self, p, c):
+        p, c = O.f32(p), O.f32(c)
+        self.host.add_light(p, c)
+        self.orc.L.orc_add_light(self.orc.h, p.ctypes.data, c.ctypes.data)
+
+
+def _placement(rng, spread=1.0):
+    M = rt.translate((rng.uniform(-4, 4) * spread, rng.uniform(-2, 3), rng.uniform(6, 14)))
+    M = rt.rotate(rng.uniform(0, 6.28), rng.normal(size=3), M)
+    return rt.scale(rng.uniform(0.6, 1.8, 3), M)
+
+
+def _material(rng, kind):
+    col = rng.uniform(0.1, 1.0, 3)
+    if kind == "mirror":
+        return rt.Material(ambient=0.05 * col, diffuse=col, specular=0.5, shininess=20.0, reflectiveness=float(rng.uniform(0.2, 0.7)))
+    if kind == "glass":
+        return rt.Material(ambient=0.02 * col, diffuse=col, specular=0.3, shininess=50.0,
+                           refractiveness=float(rng.choice([1.5, 0.825, 1.2])), refractive_ratio=float(rng.uniform(0.1, 0.5)))
+    if kind == "shiny":
+        return rt.Material(ambient=0.05 * col, diffuse=col, specular=float(rng.uniform(0.1, 1.0)), shininess=float(rng.uniform(1, 80)))
+    return rt.Material(ambient=0.05 * col, diffuse=col)
+
+
+def _soup(rng, n):
+    """n triangles scattered in a cube of side 3; shading normals = the face normal, turned towards the
+    camera side for two thirds of them (the others are back faces as seen from the camera)."""
+    c = rng.uniform(-1.5, 1.5, (n, 1, 3))
+    p = c + rng.uniform(-0.5, 0.5, (n, 3, 3))
+    fn = np.cross(p[:, 1] - p[:, 0], p[:, 2] - p[:, 0])
+    fn /= np.maximum(np.linalg.norm(fn, axis=1, keepdims=True), 1e-20)
+    flip = (fn[:, 2] > 0) ^ (rng.uniform(size=n) < 1 / 3)
+    fn[flip] *= -1
+    return p.reshape(n, 9).astype(np.float32), np.repeat(fn[:, None, :], 3, 1).reshape(n, 9).astype(np.float32)
+
+
+def _shell(rng, nu, nv):
+    """A closed, smooth, outward-oriented surface (a bumpy ellipsoid) as quads split into triangles, with
+    smooth vertex normals: the from-outside rule, the Box gate and refraction all see a proper solid."""
+    u = np.linspace(0, np.pi, nu + 1)[:, None]
+    v = np.linspace(0, 2 * np.pi, nv + 1)[None, :]
+    r = 1.0 + 0.15 * np.sin(3 * u) * np.cos(2 * v)
+    P = np.stack([r * np.sin(u) * np.cos(v), r * np.cos(u) + 0 * v, r * np.sin(u) * np.sin(v)], -1)
+    Nn = P / np.maximum(np.linalg.norm(P, axis=-1, keepdims=True), 1e-20)
+    pos, nrm = [], []
+    for i in range(nu):
+        for j in range(nv):
+            q = [(i, j), (i + 1, j), (i + 1, j + 1), (i, j + 1)]
+            for a, b, c in ((0, 2, 1), (0, 3, 2)):  # outward winding
+                pos.append(np.concatenate([P[q[a]], P[q[b]], P[q[c]]]))
+                nrm.append(np.concatenate([Nn[q[a]], Nn[q[b]], Nn[q[c]]]))
+    return np.asarray(pos, np.float32), np.asarray(nrm, np.float32)
+
+
+def build(seed):
+    """-> (ScenePair, description string)"""
+    rng = np.random.default_rng(1000 + seed)
+    sp = ScenePair()
+    what = []
+    checker = sp.checker() if seed % 2 == 0 else -1
+    rainbow = sp.rainbow() if seed % 3 == 0 else -1
+    floor = _material(rng, "mirror" if seed % 4 == 1 else "diffuse")
+    if checker >= 0:
+        floor.texture = checker
+    sp.plane((0, -3, 0), (0, 1, 0), floor)
+    n = rng.normal(size=3); n[2] = -abs(n[2]) - 0.5; n /= np.linalg.norm(n)
+    back = _material(rng, "diffuse")
+    if rainbow >= 0:
+        back.texture = rainbow
+    sp.plane((0, 0, 22), n, back)
+    if seed % 2:
+        sp.plane((-9, 0, 0), (1, 0, 0), _material(rng, "shiny"))
+    kinds = ["diffuse", "shiny", "mirror", "glass"]
+    for k in range(int(rng.integers(0, 4))):
+        sp.sphere(_placement(rng), _material(rng, kinds[(seed + k) % 4]))
+        what.append("sphere")
+    for k in range(int(rng.integers(0, 3))):
+        sp.cone(_placement(rng), _material(rng, kinds[(seed + k + 1) % 4]))
+        what.append("cone")
+    for k in range(int(rng.integers(1, 3))):
+        boxed = bool(rng.integers(0, 2))
+        if (seed + k) % 2:
+            pos, nrm = _soup(rng, int(rng.integers(40, 250)))
+            m = _material(rng, kinds[(seed + k) % 2])
+        else:
+            pos, nrm = _shell(rng, int(rng.integers(5, 12)), int(rng.integers(6, 16)))
+            m = _material(rng, kinds[(seed + k) % 4])
+        sp.mesh(pos, nrm, _placement(rng, 0.7), m, boxed)
+        what.append(("boxed " if boxed else "") + "mesh")
+    for k in range(int(rng.integers(1, 4))):
+        sp.light((rng.uniform(-8, 8), rng.uniform(4, 14), rng.uniform(-4, 12)), rng.uniform(0.2, 1.0, 3))
+    return sp, f"seed {seed}: " + ", ".join(what)
+
+
+def rays(sp, seed, w=72, h=54, n_random=1200):
+    """Camera rays of a small frame, rays aimed at mesh vertices and edge midpoints, and random rays from random origins."""
+    import parity
+    rng = np.random.default_rng(2000 + seed)
+    o, d, _ = O.camera_rays(w, h)
+    t = parity.mesh_world_targets(sp.host.flatten().contents, rng, per_mesh=150)
+    ro = rng.uniform(-6, 6, (n_random, 3)) * np.array([1, 0.5, 1]) + np.array([0, 2, 8])
+    rd = rng.normal(size=(n_random, 3))
+    return (np.concatenate([o, np.zeros_like(t), ro]).astype(np.float32),
+            np.concatenate([d, t, rd]).astype(np.float32))

@@ -405,3 +405,28 @@ def test_render_kernel_choice_by_timing_keeps_the_pixels(gpu_ctx):
     assert variants[:2] == [0, 1] and variants[2] in (0, 1) and variants[3] == variants[2]
     for rgb, rgb8 in frames[1:]:
         assert np.array_equal(rgb8, frames[0][1]) and np.array_equal(rgb, frames[0][0], equal_nan=True)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_scene_equals_oracle_on_gpu(seed):
+    """Random mixes of every object kind, transformation and material (tests/random_scenes.py): hit records
+    and radiance of rt_trace_rays against the oracle, with the tree and with the linear scan, and a small
+    frame of rt_render against the oracle's."""
+    import random_scenes
+    sp, what = random_scenes.build(seed)
+    o, d = random_scenes.rays(sp, seed)
+    ref = sp.orc.find_closest_hit(o, d)
+    ref_rad, _ = sp.orc.trace_rays(o, d, 6)
+    ref_rgb, ref_rgb8, _ = sp.orc.render(96, 72, mode=rt.MODE_REF_AA9, max_depth=6)
+    ctx = rt.Context(0)
+    try:
+        ctx.upload(sp.host)
+        for accel in (rt.ACCEL_LBVH, rt.ACCEL_BRUTE):
+            hits, rad = ctx.trace_rays(o, d, 6, accel)
+            parity.check_hits(ref, hits, what)
+            parity.check_radiance(ref_rad, rad, what)
+        rgb, rgb8 = ctx.render(96, 72, mode=rt.MODE_REF_AA9, max_depth=6)
+    finally:
+        ctx.close()
+    parity.check_radiance(ref_rgb, rgb, what)
+    parity.check_rgb8(ref_rgb8, rgb8, what)

@@ -7,6 +7,7 @@ import pytest
 import oracle_lib as O
 import parity
 import ray_tracer_amd as rt
+import random_scenes
 import twin_lib as T
 
 PRESETS = ["analytic", "teapot", "teapot_head", "shells", "textured"]
@@ -123,6 +124,22 @@ def test_tall_tree_equals_brute_force():
     assert a.tobytes() == b.tobytes() and np.array_equal(ra, rb, equal_nan=True)
     assert (a["hit"] == 1).all() and (a["object"] == 0).sum() > 1000  # most rays end on the mesh
     assert 1 <= deepest <= height
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_scene_equals_oracle(seed):
+    """Random mixes of every object kind, transformation and material: the twin (tree and linear scan) against
+    the oracle on camera rays, rays through mesh vertices and edge midpoints, and random rays."""
+    sp, what = random_scenes.build(seed)
+    o, d = random_scenes.rays(sp, seed)
+    ref = sp.orc.find_closest_hit(o, d)
+    ref_rad, _ = sp.orc.trace_rays(o, d, 6)
+    tw = T.Twin(sp.host)
+    for accel in (rt.ACCEL_LBVH, rt.ACCEL_BRUTE):
+        hits, rad = tw.trace_rays(o, d, 6, accel)
+        parity.check_hits(ref, hits, what)
+        parity.check_radiance(ref_rad, rad, what)
+    assert (ref["hit"] == 1).mean() > 0.5
 
 
 def C_byref(x):
