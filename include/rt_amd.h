@@ -206,8 +206,10 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *scene);
  * (main.cpp:1212-1288). */
 int rt_scene_update(rt_ctx *ctx, const rt_scene_desc *scene);
 
-/* Builds one Morton-code LBVH per mesh on the GPU (replaces the linear fragment scan of
- * Mesh::intersect, main.cpp:534-539, with identical closest-hit results).  Idempotent. */
+/* Builds one bounding-volume tree per mesh on the GPU, in the mesh's own space (replaces the linear
+ * fragment scan of Mesh::intersect, main.cpp:534-539, with identical closest-hit results): leaves in
+ * Morton order, topology by binned surface-area splits (environment RT_BUILD=radix: the radix tree
+ * over the Morton codes instead).  Idempotent. */
 int rt_build_accel(rt_ctx *ctx);
 
 /* Replaces main()'s pixel loop (main.cpp:1237-1273) including toneMapping (main.cpp:1184-1189) and

@@ -202,7 +202,8 @@ struct MeshHead {
     int32_t same_xform;              // the Box and the mesh share one transformation (always so in the reference's scenes)
     int32_t tri_offset, node_offset;
     int32_t gate_tri_offset;         // first of this mesh's 12 gate triangles in DevScene::gate_tri
-    int32_t pad[3];
+    int32_t root;                    // the tree's root node (mesh-relative, like the child links)
+    int32_t pad[2];
 };
 struct alignas(64) DevMesh : MeshHead {
     float to_local[12];
@@ -645,7 +646,7 @@ RT_HD void bvh_closest_packet(const DevScene &S, const MeshHead &m, v3 o, v3 d, 
     const bool one_octant = (negx == 0 || negx == wants) & (negy == 0 || negy == wants) & (negz == 0 || negz == wants);
     if (one_octant) nodes += (size_t)((negx != 0 ? 1 : 0) | (negy != 0 ? 2 : 0) | (negz != 0 ? 4 : 0)) * (size_t)(m.tri_count - 1);
     int sp = 0;  // wave-uniform stack height
-    int32_t cur = m.tri_count == 1 ? ~0 : 0;
+    int32_t cur = m.tri_count == 1 ? ~0 : m.root;
     bool in = want;
     for (;;) {
         if (cur >= 0) {

@@ -136,7 +136,7 @@ __global__ void k_children(const unsigned long long *keys, int n, int32_t *c0, i
 // so a workgroup barrier is enough to order a pass after the previous one.
 __global__ __launch_bounds__(1024) void k_fit(int n, const int32_t *c0s, const int32_t *c1s, const float *leaf_box, float pad,
                                               int32_t *done_pass, float *node_lo, float *node_hi, int32_t *height,
-                                              BvhNode *nodes, int32_t *root_height) {
+                                              BvhNode *nodes, int32_t root, int32_t *root_height) {
     __shared__ int s_left;
     int n_int = n - 1;
     for (int i = threadIdx.x; i < n_int; i += blockDim.x) done_pass[i] = 0;
@@ -154,7 +154,113 @@ __global__ __launch_bounds__(1024) void k_fit(int n, const int32_t *c0s, const i
         __syncthreads();
         if (remaining == 0) break;
     }
-    if (threadIdx.x == 0) *root_height = n_int > 0 ? height[0] : 0;
+    if (threadIdx.x == 0) *root_height = n_int > 0 ? height[root] : 0;
+}
+
+// ---- top-down build with binned surface-area splits (rt_lbvh.h), one level of the tree per launch.
+// A wave takes one node (a job: a range of the leaf permutation): centre bounds by a strided loop and a
+// wave reduction, bins in the wave's own LDS (integer atomics on order-preserving keys, so the result does
+// not depend on the order of arrival), one lane per candidate split, a 64-bit minimum over (cost, candidate)
+// for the winner, and an order-preserving partition by ballots into the other permutation buffer.  The
+// children's ranges become jobs of the next level; a child that is one leaf is linked at once.
+struct SahJob { int32_t first, last, slot, depth; };  // slot: 2 * parent id + side of the link to fill in, -1 for the root
+constexpr int kSahWaves = 4;
+__device__ __forceinline__ int32_t float_to_ordered(float f) { int32_t i = __float_as_int(f); return i ^ ((i >> 31) & 0x7fffffff); }
+__device__ __forceinline__ float ordered_to_float(int32_t i) { return __int_as_float(i ^ ((i >> 31) & 0x7fffffff)); }
+__device__ __forceinline__ void wave_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+
+__global__ __launch_bounds__(64 * kSahWaves) void k_sah_level(const SahJob *jobs, int n_jobs, const float *leaf_box, const int32_t *idx_in,
+                                                             int32_t *idx_out, int32_t *c0, int32_t *c1, SahJob *next_jobs,
+                                                             int32_t *next_count, int32_t *root) {
+    __shared__ int32_t s_bins[kSahWaves][3][kSahBins][6];
+    __shared__ int32_t s_cnt[kSahWaves][3][kSahBins];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int j = blockIdx.x * kSahWaves + wave;
+    if (j >= n_jobs) return;  // the whole wave; nothing below synchronises across waves
+    const SahJob job = jobs[j];
+    const int len = job.last - job.first + 1;
+    // centre bounds
+    float clo[3] = {INFINITY, INFINITY, INFINITY}, chi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int k = job.first + lane; k <= job.last; k += 64) {
+        int q = idx_in[k];
+        for (int a = 0; a < 3; a++) { float c = sah_centre(leaf_box, q, a); clo[a] = fminf(clo[a], c); chi[a] = fmaxf(chi[a], c); }
+    }
+    for (int off = 32; off >= 1; off >>= 1)
+        for (int a = 0; a < 3; a++) { clo[a] = fminf(clo[a], __shfl_xor(clo[a], off)); chi[a] = fmaxf(chi[a], __shfl_xor(chi[a], off)); }
+    float ext[3];
+    bool usable[3];
+    for (int a = 0; a < 3; a++) { ext[a] = chi[a] - clo[a]; usable[a] = ext[a] > 0 && ext[a] < INFINITY; }
+    int best = -1;      // winning candidate: axis * (kSahBins - 1) + bin, -1: split at the median
+    int32_t n_left = 0;
+    if (job.depth < kSahDepthLimit && (usable[0] || usable[1] || usable[2])) {
+        int32_t *bins = &s_bins[wave][0][0][0], *cnt = &s_cnt[wave][0][0];
+        for (int i = lane; i < 3 * kSahBins * 6; i += 64) bins[i] = float_to_ordered((i % 6) < 3 ? INFINITY : -INFINITY);
+        for (int i = lane; i < 3 * kSahBins; i += 64) cnt[i] = 0;
+        wave_lds_fence();
+        for (int k = job.first + lane; k <= job.last; k += 64) {
+            int q = idx_in[k];
+            for (int a = 0; a < 3; a++) {
+                if (!usable[a]) continue;
+                int b = sah_bin(sah_centre(leaf_box, q, a), clo[a], ext[a]);
+                for (int c = 0; c < 3; c++) {
+                    float lo = leaf_box[6 * q + c], hi = leaf_box[6 * q + 3 + c];
+                    if (lo == lo) atomicMin(&s_bins[wave][a][b][c], float_to_ordered(lo));  // fminf / fmaxf skip a NaN
+                    if (hi == hi) atomicMax(&s_bins[wave][a][b][3 + c], float_to_ordered(hi));
+                }
+                atomicAdd(&s_cnt[wave][a][b], 1);
+            }
+        }
+        wave_lds_fence();
+        for (int i = lane; i < 3 * kSahBins * 6; i += 64) bins[i] = __float_as_int(ordered_to_float(bins[i]));
+        wave_lds_fence();
+        unsigned long long key = ~0ull;
+        int32_t my_left = 0;
+        if (lane < 3 * (kSahBins - 1)) {
+            int a = lane / (kSahBins - 1), b = lane % (kSahBins - 1);
+            if (usable[a]) {
+                float cost = sah_split_cost(reinterpret_cast<const float *>(&s_bins[wave][a][0][0]), &s_cnt[wave][a][0], b, my_left);
+                if (cost < INFINITY) key = ((unsigned long long)(uint32_t)__float_as_int(cost) << 32) | (unsigned long long)lane;
+            }
+        }
+        unsigned long long m = key;
+        for (int off = 32; off >= 1; off >>= 1) {
+            unsigned long long o = __shfl_xor(m, off);
+            m = o < m ? o : m;
+        }
+        if (m != ~0ull) {
+            best = (int)(m & 0xffffffffull);
+            n_left = __shfl(my_left, best);
+        }
+    }
+    const int32_t total_left = best < 0 ? (len + 1) / 2 : n_left;
+    const int axis = best < 0 ? 0 : best / (kSahBins - 1), bin = best < 0 ? 0 : best % (kSahBins - 1);
+    const float lo_a = axis == 0 ? clo[0] : axis == 1 ? clo[1] : clo[2], ext_a = axis == 0 ? ext[0] : axis == 1 ? ext[1] : ext[2];
+    // order-preserving partition into the other buffer
+    int lbase = job.first, rbase = job.first + total_left;
+    int32_t only_left = 0, only_right = 0;
+    for (int k0 = job.first; k0 <= job.last; k0 += 64) {
+        int k = k0 + lane;
+        bool act = k <= job.last;
+        int q = act ? idx_in[k] : 0;
+        bool left = act && (best < 0 ? (k - job.first) < total_left : sah_bin(sah_centre(leaf_box, q, axis), lo_a, ext_a) <= bin);
+        bool right = act && !left;
+        unsigned long long ml = __builtin_amdgcn_ballot_w64(left), mr = __builtin_amdgcn_ballot_w64(right);
+        unsigned long long below = (1ull << lane) - 1ull;
+        if (left) idx_out[lbase + __popcll(ml & below)] = q;
+        if (right) idx_out[rbase + __popcll(mr & below)] = q;
+        if (ml) only_left = __shfl(q, __ffsll((long long)ml) - 1);
+        if (mr) only_right = __shfl(q, 63 - __clzll((long long)mr));
+        lbase += __popcll(ml); rbase += __popcll(mr);
+    }
+    if (lane != 0) return;
+    const int32_t g = job.first + total_left - 1;  // this node's id
+    if (job.slot < 0) *root = g;
+    else if (job.slot & 1) c1[job.slot >> 1] = g;
+    else c0[job.slot >> 1] = g;
+    if (total_left == 1) c0[g] = ~only_left;
+    else { SahJob nj = {job.first, g, 2 * g, job.depth + 1}; next_jobs[atomicAdd(next_count, 1)] = nj; }
+    if (len - total_left == 1) c1[g] = ~only_right;
+    else { SahJob nj = {g + 1, job.last, 2 * g + 1, job.depth + 1}; next_jobs[atomicAdd(next_count, 1)] = nj; }
 }
 
 // ------------------------------------------------------------------ render kernels
@@ -356,6 +462,7 @@ struct rt_ctx {
     int split_min_taps = 32;  // taps per pixel from which k_render_split is used for scenes with meshes
     bool split_forced = false;  // RT_SPLIT_MIN_TAPS (tests, tuning) sets the threshold for every scene
     int n_cus = 256;            // compute units of the device
+    bool radix_tree = false;    // RT_BUILD=radix: the Morton radix tree instead of the surface-area splits
     // Which of the two render kernels (0: k_render, 1: k_render_split; same pixels bit for bit) is faster for
     // the current frame parameters: each is timed once, on the first two launches with these parameters.
     struct Tune {
@@ -423,6 +530,7 @@ extern "C" int rt_context_create(int device, rt_ctx **out) {
         for (int k = 0; k < 2; k++)
             if (hipEventCreate(&ctx->tune.ev[v][k]) != hipSuccess) { delete ctx; return RT_ERR_HIP; }
     if (hipDeviceGetAttribute(&ctx->n_cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || ctx->n_cus <= 0) ctx->n_cus = 256;
+    if (const char *e = std::getenv("RT_BUILD")) ctx->radix_tree = std::strcmp(e, "radix") == 0;
     if (const char *e = std::getenv("RT_SPLIT_MIN_TAPS")) { ctx->split_min_taps = std::atoi(e); ctx->split_forced = true; }
     void *c = nullptr;
     if (hipMalloc(&c, (size_t)kCounterStripes * kCounterStride * sizeof(unsigned long long)) != hipSuccess ||
@@ -676,6 +784,8 @@ extern "C" int rt_build_accel(rt_ctx *ctx) {
     unsigned long long *d_keys = nullptr;
     int32_t *d_c0 = nullptr, *d_c1 = nullptr, *d_done = nullptr, *d_height = nullptr, *d_root = nullptr;
     float *d_lo = nullptr, *d_hi = nullptr, *d_bounds = nullptr;
+    int32_t *d_idx[2] = {nullptr, nullptr}, *d_sah_count = nullptr;
+    SahJob *d_jobs[2] = {nullptr, nullptr};
     int rc;
     std::vector<void *> tmp;
     auto cleanup = [&]() { for (void *p : tmp) (void)hipFree(p); };
@@ -691,6 +801,13 @@ extern "C" int rt_build_accel(rt_ctx *ctx) {
     TMP_ALLOC(d_lo, 3 * (size_t)max_n);
     TMP_ALLOC(d_hi, 3 * (size_t)max_n);
     TMP_ALLOC(d_bounds, 6 * (size_t)ctx->meshes.size() + 6);
+    if (!ctx->radix_tree) {
+        TMP_ALLOC(d_idx[0], (size_t)max_n);
+        TMP_ALLOC(d_idx[1], (size_t)max_n);
+        TMP_ALLOC(d_jobs[0], (size_t)max_n);
+        TMP_ALLOC(d_jobs[1], (size_t)max_n);
+        TMP_ALLOC(d_sah_count, 2);
+    }
 #undef TMP_ALLOC
     std::vector<float> bounds(6 * ctx->meshes.size() + 6, 0.0f);
     for (size_t i = 0; i < ctx->meshes.size(); i++)
@@ -715,17 +832,44 @@ extern "C" int rt_build_accel(rt_ctx *ctx) {
                            ctx->d_ref_tri, ctx->d_tri_pos, ctx->d_tri_frag, ctx->d_tri_sub, ctx->d_tri_test, ctx->d_tri_key,
                            ctx->d_tri_orig, ctx->d_leaf_box);
         if (n >= 2) {
-            hipLaunchKernelGGL(k_children, dim3((n + 255) / 256), blk, 0, ctx->stream, d_keys, n, d_c0, d_c1);
+            int32_t root = 0;
+            if (ctx->radix_tree) {
+                hipLaunchKernelGGL(k_children, dim3((n + 255) / 256), blk, 0, ctx->stream, d_keys, n, d_c0, d_c1);
+            } else {
+                // top-down, one launch per level; the number of jobs of the next level comes back each time
+                std::vector<int32_t> iota(n);
+                for (int k = 0; k < n; k++) iota[k] = k;
+                SahJob first_job = {0, n - 1, -1, 0};
+                e = hipMemcpyAsync(d_idx[0], iota.data(), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream);
+                if (e == hipSuccess) e = hipMemcpyAsync(d_jobs[0], &first_job, sizeof first_job, hipMemcpyHostToDevice, ctx->stream);
+                int n_jobs = 1, cur = 0;
+                for (int level = 0; e == hipSuccess && n_jobs > 0; level++, cur ^= 1) {
+                    if (level > kSahDepthLimit + 40) { e = hipErrorUnknown; break; }  // cannot happen: the height is bounded
+                    e = hipMemsetAsync(d_sah_count, 0, sizeof(int32_t), ctx->stream);
+                    if (e != hipSuccess) break;
+                    hipLaunchKernelGGL(k_sah_level, dim3((n_jobs + kSahWaves - 1) / kSahWaves), dim3(64 * kSahWaves), 0, ctx->stream,
+                                       d_jobs[cur], n_jobs, ctx->d_leaf_box + 6 * (size_t)m.tri_offset, d_idx[cur], d_idx[cur ^ 1], d_c0, d_c1,
+                                       d_jobs[cur ^ 1], d_sah_count, d_sah_count + 1);
+                    e = hipMemcpyAsync(&n_jobs, d_sah_count, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream);
+                    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+                }
+                if (e == hipSuccess) e = hipMemcpy(&root, d_sah_count + 1, sizeof(int32_t), hipMemcpyDeviceToHost);
+                if (e != hipSuccess) break;
+            }
+            ctx->mesh_build[i].root = root;
+            ctx->meshes[i].root = root;
             hipLaunchKernelGGL(k_fit, dim3(1), dim3(1024), 0, ctx->stream, n, d_c0, d_c1,
                                ctx->d_leaf_box + 6 * (size_t)m.tri_offset, ctx->mesh_build[i].pad, d_done, d_lo, d_hi, d_height,
-                               ctx->d_nodes + m.node_offset, d_root + i);
+                               ctx->d_nodes + m.node_offset, root, d_root + i);
             int nv = (n - 1) * (kOctants - 1);
             hipLaunchKernelGGL(k_octant_variants, dim3((nv + 255) / 256), blk, 0, ctx->stream, ctx->d_nodes + m.node_offset, n - 1);
         }
     }
     (void)hipEventRecord(ctx->ev1, ctx->stream);
-    e = hipGetLastError();
+    if (e == hipSuccess) e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess)  // the roots
+        e = hipMemcpy(ctx->d_meshes, ctx->meshes.data(), ctx->meshes.size() * sizeof(DevMesh), hipMemcpyHostToDevice);
     std::vector<int32_t> roots(ctx->meshes.size() + 1, 0);
     if (e == hipSuccess) e = hipMemcpy(roots.data(), d_root, roots.size() * sizeof(int32_t), hipMemcpyDeviceToHost);
     cleanup();

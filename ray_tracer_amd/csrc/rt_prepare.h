@@ -20,6 +20,7 @@ struct MeshBuild {
     float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};  // bounds of the finite vertices (Morton normalisation)
     float pad = 0;                                // leaf box padding
     int height = 0;                               // LBVH height after the build
+    int root = 0;                                 // root node after the build
 };
 
 // The leaves of a mesh's LBVH ("references").  A triangle whose box is much larger than the mesh's
@@ -201,9 +202,10 @@ inline int prepare_meshes(const rt_scene_desc *sc, std::vector<DevMesh> &meshes,
             mb.ref_count = (int)ref_tri.size() - mb.ref_offset;
         } else {
             mb.ref_offset = previous[i].ref_offset; mb.ref_count = previous[i].ref_count;
+            mb.root = previous[i].root; mb.height = previous[i].height;
         }
         dm.tri_offset = mb.ref_offset; dm.tri_count = mb.ref_count; dm.boxed = m.boxed;  // what the kernels walk: references
-        dm.node_offset = node_total; dm.gate_tri_offset = 12 * i;
+        dm.node_offset = node_total; dm.gate_tri_offset = 12 * i; dm.root = mb.root;
         mb.node_offset = node_total;
         node_total += kOctants * std::max(mb.ref_count - 1, 0);  // one copy of the tree per ray-direction octant
         float maxabs = 0;

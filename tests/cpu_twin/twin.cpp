@@ -54,6 +54,7 @@ struct Twin {
     std::vector<std::vector<u4>> texels;
     std::vector<float> srgb_lut;
     int bvh_max_depth = 0;
+    std::vector<std::vector<int32_t>> kids;  // per mesh: c0[n-1] then c1[n-1]
     Work total{};
 };
 
@@ -66,6 +67,66 @@ void gather(Twin &t, const DevMesh &m, const std::vector<uint64_t> *keys) {
         t.tri_orig[m.tri_offset + k] = orig;
         piece_box(&t.ref_pos[9 * (size_t)(m.tri_offset + local)], &t.leaf_box[6 * (size_t)(m.tri_offset + k)]);
     }
+}
+
+// The top-down build of k_sah_level (binned surface-area splits, rt_lbvh.h), one job after the other:
+// the same bins, costs, tie rule, order-preserving partition and node ids.  Returns the root's id.
+int32_t sah_children(int n, const float *leaf_box, std::vector<int32_t> &c0, std::vector<int32_t> &c1) {
+    struct Job { int first, last, slot, depth; };
+    std::vector<int32_t> idx(n), tmp(n);
+    for (int k = 0; k < n; k++) idx[k] = k;
+    std::vector<Job> level{{0, n - 1, -1, 0}}, next;
+    int32_t root = 0;
+    while (!level.empty()) {
+        next.clear();
+        for (const Job &j : level) {
+            const int len = j.last - j.first + 1;
+            float clo[3] = {INFINITY, INFINITY, INFINITY}, chi[3] = {-INFINITY, -INFINITY, -INFINITY}, ext[3];
+            bool usable[3];
+            for (int k = j.first; k <= j.last; k++)
+                for (int a = 0; a < 3; a++) { float c = sah_centre(leaf_box, idx[k], a); clo[a] = fminf(clo[a], c); chi[a] = fmaxf(chi[a], c); }
+            for (int a = 0; a < 3; a++) { ext[a] = chi[a] - clo[a]; usable[a] = ext[a] > 0 && ext[a] < INFINITY; }
+            int best = -1;
+            int32_t n_left = 0;
+            float best_cost = INFINITY;
+            if (j.depth < kSahDepthLimit)
+                for (int a = 0; a < 3; a++) {
+                    if (!usable[a]) continue;
+                    float bins[kSahBins * 6];
+                    int32_t counts[kSahBins] = {0};
+                    for (int b = 0; b < kSahBins; b++)
+                        for (int c = 0; c < 6; c++) bins[6 * b + c] = c < 3 ? INFINITY : -INFINITY;
+                    for (int k = j.first; k <= j.last; k++) {
+                        int q = idx[k], b = sah_bin(sah_centre(leaf_box, q, a), clo[a], ext[a]);
+                        sah_grow(bins + 6 * b, leaf_box + 6 * (size_t)q);
+                        counts[b]++;
+                    }
+                    for (int b = 0; b < kSahBins - 1; b++) {
+                        int32_t nl;
+                        float cost = sah_split_cost(bins, counts, b, nl);
+                        if (cost < best_cost) { best_cost = cost; best = a * (kSahBins - 1) + b; n_left = nl; }
+                    }
+                }
+            const int total_left = best < 0 ? (len + 1) / 2 : n_left;
+            if (best >= 0) {
+                const int axis = best / (kSahBins - 1), bin = best % (kSahBins - 1);
+                int l = j.first, r = j.first + total_left;
+                for (int k = j.first; k <= j.last; k++) {
+                    int q = idx[k];
+                    if (sah_bin(sah_centre(leaf_box, q, axis), clo[axis], ext[axis]) <= bin) tmp[l++] = q; else tmp[r++] = q;
+                }
+                for (int k = j.first; k <= j.last; k++) idx[k] = tmp[k];
+            }
+            const int32_t g = j.first + total_left - 1;
+            if (j.slot < 0) root = g;
+            else if (j.slot & 1) c1[j.slot >> 1] = g;
+            else c0[j.slot >> 1] = g;
+            if (total_left == 1) c0[g] = ~idx[j.first]; else next.push_back({j.first, g, 2 * g, j.depth + 1});
+            if (len - total_left == 1) c1[g] = ~idx[j.last]; else next.push_back({g + 1, j.last, 2 * g + 1, j.depth + 1});
+        }
+        level.swap(next);
+    }
+    return root;
 }
 
 }  // namespace
@@ -159,6 +220,13 @@ int twin_build_accel(void *h) {
         std::vector<float> lo(3 * (size_t)(n - 1)), hi(3 * (size_t)(n - 1));
         for (int i = 0; i < n - 1; i++) lbvh_node_children(keys.data(), n, i, c0[i], c1[i]);
         const float *leaf_box = &t->leaf_box[6 * (size_t)m.tri_offset];
+        int32_t root = 0;
+        const char *builder = std::getenv("RT_BUILD");
+        if (!(builder && std::strcmp(builder, "radix") == 0)) root = sah_children(n, leaf_box, c0, c1);
+        t->build[mi].root = root;
+        t->meshes[mi].root = root;
+        t->kids.resize(t->meshes.size());
+        t->kids[mi] = c0; t->kids[mi].insert(t->kids[mi].end(), c1.begin(), c1.end());
         for (int pass = 1; pass <= 4096; pass++) {
             int left = 0;
             for (int i = 0; i < n - 1; i++)
@@ -170,8 +238,8 @@ int twin_build_accel(void *h) {
         for (int o = 1; o < kOctants; o++)
             for (int i = 0; i < n - 1; i++)
                 t->nodes[m.node_offset + (size_t)o * (n - 1) + i] = lbvh_octant_variant(t->nodes[m.node_offset + i], o);
-        t->build[mi].height = height[0];
-        t->bvh_max_depth = std::max(t->bvh_max_depth, height[0]);
+        t->build[mi].height = height[root];
+        t->bvh_max_depth = std::max(t->bvh_max_depth, height[root]);
     }
     return t->bvh_max_depth;
 }
@@ -225,6 +293,13 @@ void twin_render(void *h, const rt_render_params *p, int x0, int y0, int x1, int
             for (int k = 0; k < 10; k++) acc[k] += vals[k];
         }
     if (counters) for (int k = 0; k < 10; k++) counters[k] += acc[k];
+}
+
+int twin_copy_children(void *h, int mesh, int32_t *out) {
+    Twin *t = static_cast<Twin *>(h);
+    if (mesh >= (int)t->kids.size()) return 0;
+    std::memcpy(out, t->kids[mesh].data(), t->kids[mesh].size() * sizeof(int32_t));
+    return (int)t->kids[mesh].size();
 }
 
 // number of references (leaves) of a mesh's tree

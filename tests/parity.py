@@ -138,7 +138,9 @@ def check_lbvh(nodes, order, pos_all, tri_offset, tri_count, max_height=64, seed
         return 0
     ch = nodes[:, 12:14].copy().view(np.int32)
     assert sorted(~ch[ch < 0]) == list(range(n))
-    assert sorted(ch[ch >= 0]) == list(range(1, len(nodes)))
+    linked = sorted(ch[ch >= 0])
+    root = (set(range(len(nodes))) - set(int(c) for c in linked)).pop()  # the one node nobody links to
+    assert linked == [i for i in range(len(nodes)) if i != root]
     box = np.stack([nodes[:, 0:6], nodes[:, 6:12]], axis=1).astype(np.float64)  # [node, side, lo|hi]
     leaf_lo = np.zeros((n, 3)); leaf_hi = np.zeros((n, 3))
     node_lo = np.zeros((len(nodes), 3)); node_hi = np.zeros((len(nodes), 3))
@@ -153,7 +155,7 @@ def check_lbvh(nodes, order, pos_all, tri_offset, tri_count, max_height=64, seed
                 parent[k] = c
     # bottom-up: children have larger depth; process nodes in order of decreasing depth
     depth = np.zeros(len(nodes), int)
-    todo = [0]
+    todo = [root]
     topo = []
     while todo:
         c = todo.pop()
@@ -175,7 +177,7 @@ def check_lbvh(nodes, order, pos_all, tri_offset, tri_count, max_height=64, seed
                 assert np.all((box[c, side, :3] <= node_lo[k]) | ~finite) and np.all((box[c, side, 3:] >= node_hi[k]) | ~finite)
                 hc = max(hc, height[k])
         height[c] = hc + 1
-    assert height[0] <= max_height
+    assert height[root] <= max_height
     # coverage of the triangles by their leaves
     rng = np.random.default_rng(seed)
     bary = np.concatenate([np.eye(3), rng.dirichlet((1, 1, 1), 13)])            # [16, 3]
@@ -186,7 +188,7 @@ def check_lbvh(nodes, order, pos_all, tri_offset, tri_count, max_height=64, seed
     np.logical_or.at(covered, tri_of_leaf - tri_offset, inside)
     ok = np.all(np.isfinite(pos_all[tri_offset:tri_offset + tri_count].reshape(tri_count, -1)), axis=1)
     assert np.all(covered[ok]), f"{int((~covered[ok]).sum())} sample points outside every leaf of their triangle"
-    return int(height[0])
+    return int(height[root])
 
 
 def deep_tree_scene(n_small=3000, seed=5):

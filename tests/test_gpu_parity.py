@@ -104,18 +104,26 @@ def test_lbvh_structure_on_gpu(gpu_ctx, host_scene):
         assert 0 < ctx.counters().bvh_max_depth <= 64
 
 
-def test_cpu_twin_and_gpu_agree_on_the_lbvh(gpu_ctx, host_scene):
-    """The serial host build and the GPU build produce the same tree (same keys, same sort, same fit)."""
+@pytest.mark.parametrize("builder", ["radix", "sah"])
+def test_cpu_twin_and_gpu_agree_on_the_lbvh(builder, host_scene, monkeypatch):
+    """The serial host build and the GPU build produce the same tree bit for bit (same keys, same sort, same
+    splits, same node ids, same fit), with the surface-area splits and with the radix tree."""
     import twin_lib as T
+    monkeypatch.setenv("RT_BUILD", builder)
     for preset in ("teapot", "shells"):  # shells: with triangles cut into pieces
         d = host_scene(preset).flatten().contents
         tw = T.Twin(host_scene(preset))
-        ctx = gpu_ctx(preset)
-        for mi in range(d.n_meshes):
-            n0, o0 = tw.copy_bvh(mi)
-            n1, o1 = ctx.copy_bvh(mi)
-            assert np.array_equal(o0, o1)
-            assert np.array_equal(n0.view(np.uint32), n1.view(np.uint32))
+        ctx = rt.Context(0)
+        try:
+            ctx.upload(host_scene(preset))
+            assert ctx.counters().bvh_max_depth == tw.height
+            for mi in range(d.n_meshes):
+                n0, o0 = tw.copy_bvh(mi)
+                n1, o1 = ctx.copy_bvh(mi)
+                assert np.array_equal(o0, o1)
+                assert np.array_equal(n0.view(np.uint32), n1.view(np.uint32))
+        finally:
+            ctx.close()
 
 
 def test_sharded_render_reassembles_bitwise(gpu_ctx):
@@ -371,21 +379,29 @@ def test_frame_pipeline_overlapped_frames_equal_serial(gpu_ctx, collective):
         assert np.array_equal(e, g, equal_nan=True)
 
 
-def test_tall_tree_equals_brute_force_on_gpu():
-    """The tall-tree mesh (Morton chain + thousands of equal codes): packet traversal and linear scan give the
-    same records and radiance, and both match the CPU twin."""
+@pytest.mark.parametrize("builder", ["radix", "sah"])
+def test_tall_tree_equals_brute_force_on_gpu(builder, monkeypatch):
+    """The tall-tree mesh (Morton chain + thousands of equal codes; 42 levels as a radix tree): packet traversal
+    and linear scan give the same records and radiance, both match the CPU twin, and both builders give the
+    twin's tree."""
     import twin_lib as T
+    monkeypatch.setenv("RT_BUILD", builder)
     hs, o, d = parity.deep_tree_scene()
     ctx = rt.Context(0)
     try:
         ctx.upload(hs)
-        assert 30 <= ctx.counters().bvh_max_depth <= 64
+        height = ctx.counters().bvh_max_depth
+        assert (30 if builder == "radix" else 1) <= height <= 64
         a, ra = ctx.trace_rays(o, d, 4, rt.ACCEL_LBVH)
         b, rb = ctx.trace_rays(o, d, 4, rt.ACCEL_BRUTE)
+        nodes, order = ctx.copy_bvh(0)
     finally:
         ctx.close()
     assert a.tobytes() == b.tobytes() and np.array_equal(ra, rb, equal_nan=True)
     tw = T.Twin(hs)
+    assert tw.height == height
+    n0, o0 = tw.copy_bvh(0)
+    assert np.array_equal(o0, order) and np.array_equal(n0.view(np.uint32), nodes.view(np.uint32))
     c, rc = tw.trace_rays(o, d, 4, rt.ACCEL_LBVH)
     parity.check_hits(c, a, "tall tree")
     parity.check_radiance(rc, ra, "tall tree")

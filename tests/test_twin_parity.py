@@ -112,12 +112,15 @@ def test_degenerate_meshes(oracle_scene):
             assert ref["frag"][2] in (0, 1)  # the shared diagonal: decided by the tie rule, equal on both sides
 
 
-def test_tall_tree_equals_brute_force():
-    """A mesh built to give a tall LBVH (Morton chain + equal codes): tree and linear scan agree on every ray,
-    and the traversal stack (one entry per level at most) holds."""
+@pytest.mark.parametrize("builder", ["radix", "sah"])
+def test_tall_tree_equals_brute_force(builder, monkeypatch):
+    """A mesh built to give a tall radix tree (Morton chain + equal codes): tree and linear scan agree on every
+    ray, and the traversal stack (one entry per level at most) holds.  The surface-area build of the same
+    leaves stays low."""
+    monkeypatch.setenv("RT_BUILD", builder)
     hs, o, d = parity.deep_tree_scene()
     tw = T.Twin(hs)
-    assert 30 <= tw.height <= 64
+    assert (30 if builder == "radix" else 1) <= tw.height <= 64
     a, ra = tw.trace_rays(o, d, 4, rt.ACCEL_LBVH)
     deepest, height = tw.max_stack, tw.height
     b, rb = tw.trace_rays(o, d, 4, rt.ACCEL_BRUTE)
