@@ -24,7 +24,8 @@ def build():
     if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-fopenmp", "-ffp-contract=off", "-fno-fast-math",
                                "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "ray_tracer_amd", "csrc"),
-                               "-shared", "-o", out, src])
+                               "-shared", "-Wl,-Bsymbolic",  # its own copies of the headers' inline functions, not the loaded library's
+                               "-o", out, src])
     return out
 
 
