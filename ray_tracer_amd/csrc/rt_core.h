@@ -1324,6 +1324,8 @@ RT_HD float tap_weight(int mode, int k) {
     int kx = k % 3, ky = k / 3;
     return (float)((kx == 1 ? 2 : 1) * (ky == 1 ? 2 : 1));
 }
+// offset of column / row a of the m x m GRID taps from the pixel's corner
+RT_HD float grid_offset(int a, int m, float s) { return ((float)a + 0.5f) / (float)m * s; }
 RT_HD v3 primary_dir(const Camera &c, int mode, int m, int i, int j, int k, float &weight) {
     float s = c.s;
     if (mode == RT_MODE_REF_1SPP) {
@@ -1341,10 +1343,21 @@ RT_HD v3 primary_dir(const Camera &c, int mode, int m, int i, int j, int k, floa
         return normalize(V3(tx, ty, 1));
     }
     int a = k % m, b = k / m;
-    float tx = dx + ((float)a + 0.5f) / (float)m * s;
-    float ty = dy - ((float)b + 0.5f) / (float)m * s;
+    float tx = dx + grid_offset(a, m, s);
+    float ty = dy - grid_offset(b, m, s);
     weight = 1.0f;
     return normalize(V3(tx, ty, 1));
+}
+// The same GRID tap from a table of the m offsets (grid_off[a] = grid_offset(a, m, s)) and the tap's column
+// and row: no integer division and no float division per tap.
+RT_HD v3 primary_dir_grid(const Camera &c, int i, int j, float off_x, float off_y) {
+    float s = c.s;
+    float dx = c.X + i * s, dy = c.Y - j * s;
+    return normalize(V3(dx + off_x, dy - off_y, 1));
+}
+constexpr int kMaxGrid = 64;  // largest m of the GRID mode
+RT_HD void fill_grid_offsets(float *grid_off, int m, float s) {
+    for (int a = 0; a < kMaxGrid; a++) grid_off[a] = a < m ? grid_offset(a, m, s) : 0.0f;
 }
 // toneMapping, main.cpp:1184-1189
 RT_HD v3 tone_map(v3 c) {
@@ -1358,12 +1371,20 @@ RT_HD uint8_t quantise(float c) { return (uint8_t)(int)(float)(255 * c); }
 struct PixelTaps {
     Camera cam;
     int mode, grid_m, taps, i, j, k;
+    int col, row;           // GRID: k = row * grid_m + col
+    const float *grid_off;  // GRID: grid_offset(a, grid_m, cam.s) for a < grid_m
     float wt;
     v3 color;
     RT_HD bool next(v3 &ro, v3 &rd) {
         if (k >= taps) return false;
         ro = V3(0, 0, 0);
-        rd = primary_dir(cam, mode, grid_m, i, j, k, wt);
+        if (mode == RT_MODE_GRID) {
+            rd = primary_dir_grid(cam, i, j, grid_off[col], grid_off[row]);
+            wt = 1.0f;
+            if (++col == grid_m) { col = 0; row++; }
+        } else {
+            rd = primary_dir(cam, mode, grid_m, i, j, k, wt);
+        }
         k++;
         return true;
     }
@@ -1373,10 +1394,10 @@ struct PixelTaps {
 };
 template <int F, bool COUNT, class Stack>
 RT_HD v3 render_pixel(const DevScene &S, const Camera &cam, int mode, int grid_m, int max_depth, int accel,
-                      int i, int j, Stack &stk, Work &wk) {
+                      int i, int j, const float *grid_off, Stack &stk, Work &wk) {
     PixelTaps src;
     src.cam = cam; src.mode = mode; src.grid_m = grid_m; src.taps = taps_of(mode, grid_m);
-    src.i = i; src.j = j; src.k = 0; src.wt = 1.0f; src.color = V3(0, 0, 0);
+    src.i = i; src.j = j; src.k = 0; src.col = 0; src.row = 0; src.grid_off = grid_off; src.wt = 1.0f; src.color = V3(0, 0, 0);
     trace_loop<F, COUNT>(S, max_depth, accel, stk, wk, src);
     return src.result();
 }

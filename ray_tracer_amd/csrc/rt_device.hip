@@ -44,6 +44,9 @@ constexpr int kCounterStripes = 4096, kCounterStride = 16;
 constexpr int render_waves(int features, bool count) {
     return count ? 4 : features == F_MESH ? 5 : features == (F_QUADRIC | F_SECONDARY) ? 5 : 4;
 }
+// k_render_split holds a round's radiance in LDS as well: with the larger parking area of the variants with
+// secondary rays only four blocks fit a compute unit
+constexpr int split_waves(int features, bool count) { return (features & F_SECONDARY) ? 4 : render_waves(features, count); }
 constexpr int kWavesPerBlock = kBlock / 64;
 constexpr int kStackWords = 3 * kStackDepth;
 struct WaveStack {
@@ -293,7 +296,10 @@ __global__ __launch_bounds__(kBlock, render_waves(F, COUNT)) void k_render(DevSc
     work_zero(wk);
     v3 color = V3(0, 0, 0);
     bool inside = tile < a.tiles_total && i < a.width && j < a.height;
-    if (inside) color = render_pixel<F, COUNT>(S, a.cam, a.mode, a.grid_m, a.max_depth, a.accel, i, j, stk, wk);
+    __shared__ float s_grid_off[kMaxGrid];
+    if (threadIdx.x < kMaxGrid) s_grid_off[threadIdx.x] = (int)threadIdx.x < a.grid_m ? grid_offset(threadIdx.x, a.grid_m, a.cam.s) : 0.0f;
+    __syncthreads();
+    if (inside) color = render_pixel<F, COUNT>(S, a.cam, a.mode, a.grid_m, a.max_depth, a.accel, i, j, s_grid_off, stk, wk);
     size_t p = ((size_t)blockIdx.x * (RT_TILE_W * RT_TILE_H) + (size_t)py * RT_TILE_W + px) * 3;
     if (rgb_tiles) { rgb_tiles[p] = color.x; rgb_tiles[p + 1] = color.y; rgb_tiles[p + 2] = color.z; }
     if (rgb8_tiles) {
@@ -315,12 +321,20 @@ constexpr int kRoundTaps = 8;
 struct TapSlice {  // a trace_loop source: taps [k, k_end) of one pixel
     Camera cam;
     int mode, grid_m, i, j, k, k_end, base;
+    int col, row;           // GRID: k = row * grid_m + col
+    const float *grid_off;  // GRID: the block's table of grid_offset(a, grid_m, cam.s)
     float wt;
     float *slots;  // this lane's column of the LDS array [kRoundTaps][3][64]
     __device__ bool next(v3 &ro, v3 &rd) {
         if (k >= k_end) return false;
         ro = V3(0, 0, 0);
-        rd = primary_dir(cam, mode, grid_m, i, j, k, wt);
+        if (mode == RT_MODE_GRID) {
+            rd = primary_dir_grid(cam, i, j, grid_off[col], grid_off[row]);
+            wt = 1.0f;
+            if (++col == grid_m) { col = 0; row++; }
+        } else {
+            rd = primary_dir(cam, mode, grid_m, i, j, k, wt);
+        }
         k++;
         return true;
     }
@@ -332,10 +346,13 @@ struct TapSlice {  // a trace_loop source: taps [k, k_end) of one pixel
 };
 
 template <int F, bool COUNT>
-__global__ __launch_bounds__(kBlock, render_waves(F, COUNT)) void k_render_split(DevScene S, RenderArgs a, float *rgb_tiles,
+__global__ __launch_bounds__(kBlock, split_waves(F, COUNT)) void k_render_split(DevScene S, RenderArgs a, float *rgb_tiles,
                                                                                  uint8_t *rgb8_tiles, unsigned long long *counters) {
     RT_WAVE_STACK(stk, F);
     __shared__ float tap_lds[kRoundTaps * 3 * 64];
+    __shared__ float s_grid_off[kMaxGrid];
+    if (threadIdx.x < kMaxGrid) s_grid_off[threadIdx.x] = (int)threadIdx.x < a.grid_m ? grid_offset(threadIdx.x, a.grid_m, a.cam.s) : 0.0f;
+    __syncthreads();
     int local = blockIdx.x >> 2, quad = blockIdx.x & 3;
     int tile = local * a.world_size + a.rank;
     int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -351,6 +368,7 @@ __global__ __launch_bounds__(kBlock, render_waves(F, COUNT)) void k_render_split
         TapSlice src;
         src.cam = a.cam; src.mode = a.mode; src.grid_m = a.grid_m; src.i = i; src.j = j; src.base = base; src.wt = 1.0f;
         src.k = base + wave * chunk;
+        src.col = src.k % a.grid_m; src.row = src.k / a.grid_m; src.grid_off = s_grid_off;  // (one division per round, not per tap)
         src.k_end = base + ((wave + 1) * chunk < n ? (wave + 1) * chunk : n);
         src.slots = tap_lds + lane;
         if (inside && src.k < src.k_end) trace_loop<F, COUNT>(S, a.max_depth, a.accel, stk, wk, src);

@@ -279,13 +279,15 @@ void twin_render(void *h, const rt_render_params *p, int x0, int y0, int x1, int
     Twin *t = static_cast<Twin *>(h);
     Camera cam = make_camera(p->width, p->height, p->fov);
     unsigned long long acc[10] = {0};
+    float grid_off[kMaxGrid];
+    fill_grid_offsets(grid_off, p->grid_m, cam.s);
 #pragma omp parallel for schedule(dynamic, 1) reduction(+ : acc[:10])
     for (int j = y0; j < y1; j++)
         for (int i = x0; i < x1; i++) {
             VecStack stk;
             Work wk;
             work_zero(wk);
-            v3 c = render_pixel<F_ALL, true>(t->S, cam, p->mode, p->grid_m, p->max_depth, p->accel, i, j, stk, wk);
+            v3 c = render_pixel<F_ALL, true>(t->S, cam, p->mode, p->grid_m, p->max_depth, p->accel, i, j, grid_off, stk, wk);
             size_t q = 3 * ((size_t)j * p->width + i);
             if (rgb) { rgb[q] = c.x; rgb[q + 1] = c.y; rgb[q + 2] = c.z; }
             if (rgb8) { v3 tm = tone_map(c); rgb8[q] = quantise(tm.x); rgb8[q + 1] = quantise(tm.y); rgb8[q + 2] = quantise(tm.z); }
