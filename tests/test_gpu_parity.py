@@ -446,3 +446,34 @@ def test_random_scene_equals_oracle_on_gpu(seed):
         ctx.close()
     parity.check_radiance(ref_rgb, rgb, what)
     parity.check_rgb8(ref_rgb8, rgb8, what)
+
+
+def test_half_a_million_triangles():
+    """A closed bumpy surface of 500 000 triangles behind a Box gate: upload, cut, sort, build (a tree of about
+    twenty levels, one launch each) and fit stay within seconds, and the tree gives the records of the linear scan."""
+    import time
+    import random_scenes
+    rng = np.random.default_rng(11)
+    pos, nrm = random_scenes._shell(rng, 500, 500)
+    assert len(pos) == 500000
+    hs = rt.HostScene()
+    hs.add_mesh_tris(pos, nrm, rt.scale(3.0, rt.translate((0, 0, 9))), rt.Material(diffuse=(0.7, 0.6, 0.3), specular=0.4, shininess=30.0),
+                     boxed=True)
+    hs.add_plane((0, -4, 0), (0, 1, 0), rt.Material(diffuse=(0.4, 0.4, 0.4)))
+    hs.add_light((6, 9, 0), 1.0)
+    ctx = rt.Context(0)
+    try:
+        t0 = time.perf_counter()
+        ctx.upload(hs)
+        dt = time.perf_counter() - t0
+        c = ctx.counters()
+        assert 15 <= c.bvh_max_depth <= 64 and dt < 20.0, (c.bvh_max_depth, dt)
+        o, d, _ = O.camera_rays(64, 48)
+        a, ra = ctx.trace_rays(o, d, 4, rt.ACCEL_LBVH)
+        b, rb = ctx.trace_rays(o, d, 4, rt.ACCEL_BRUTE)
+        assert (a["object"] == 0).sum() > 200
+        assert a.tobytes() == b.tobytes() and np.array_equal(ra, rb, equal_nan=True)
+        rgb, rgb8 = ctx.render(320, 180, mode=rt.MODE_GRID, grid_m=2)
+        assert np.isfinite(rgb).all() and rgb8.max() > 50
+    finally:
+        ctx.close()
