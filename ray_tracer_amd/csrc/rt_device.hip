@@ -1,8 +1,10 @@
 // rt_device.hip -- HIP kernels (gfx950) and the C ABI of librt_amd.so (include/rt_amd.h).
 //
 // Kernels:
-//   k_sort_keys / k_bitonic_step / k_gather_tris / k_children / k_fit   LBVH build, one per mesh
-//   k_render<COUNT>            one thread per pixel of a 16x16 tile, all taps, tile-major output
+//   k_sort_keys / k_bitonic_step / k_gather_tris     leaves of a mesh's tree in Morton order
+//   k_sah_level (or k_children) / k_fit / k_octant_variants   topology, bounds, per-octant copies
+//   k_render<FEATURES, COUNT>        one thread per pixel of a 16x16 tile, all taps, tile-major output
+//   k_render_split<FEATURES, COUNT>  the same pixels with a pixel's taps spread over a block's waves
 //   k_untile                   tile-major shards -> row-major frame
 //   k_trace_rays / k_intersect_object   arbitrary-ray entry points used for parity checks
 //
@@ -35,9 +37,6 @@ constexpr int kCounterStripes = 4096, kCounterStride = 16;
 
 // ------------------------------------------------------------------ traversal stack in LDS
 
-// The packet traversal keeps ONE stack per wave: entries of (node, 64-bit lane mask), three LDS
-// words each.  All lanes write / read the same words (a broadcast access); the values are made
-// scalar again with readfirstlane.
 // Resident waves per SIMD a render kernel variant is compiled for (register budget 512 / waves).
 // The mesh-only variant fits 96 registers and the quadric-only variant 80 without spilling (a sixth wave did not pay); the
 // others need more than 100.
@@ -49,13 +48,16 @@ constexpr int render_waves(int features, bool count) {
 constexpr int split_waves(int features, bool count) { return (features & F_SECONDARY) ? 4 : render_waves(features, count); }
 constexpr int kWavesPerBlock = kBlock / 64;
 constexpr int kStackWords = 3 * kStackDepth;
+// The packet traversal keeps ONE stack per wave: entries of (node, 64-bit lane mask), three LDS
+// words each.  All lanes write / read the same words (a broadcast access); the values are made
+// scalar again with readfirstlane.
 struct WaveStack {
     uint32_t *base;  // this wave's kStackWords words of LDS
     float *cold;     // this thread's column of the block's [kColdSlots][kBlock] parking area
     __device__ __forceinline__ void cold_put(int slot, float v) { cold[slot * kBlock] = v; }
     __device__ __forceinline__ float cold_get(int slot) const { return cold[slot * kBlock]; }
     __device__ __forceinline__ void put(int slot, int32_t node, uint64_t mask) {
-        if (slot < kStackDepth) {  // never false: the tree height is validated at build time
+        if (slot < kStackDepth) {  // never false: rt_build_accel refuses a tree higher than the stack
             base[3 * slot] = (uint32_t)node; base[3 * slot + 1] = (uint32_t)mask; base[3 * slot + 2] = (uint32_t)(mask >> 32);
         }
     }
@@ -88,7 +90,7 @@ __device__ __forceinline__ void flush_work(const Work &wk, unsigned long long *c
     }
 }
 
-// ------------------------------------------------------------------ LBVH build kernels
+// ------------------------------------------------------------------ tree build kernels
 
 __global__ void k_sort_keys(const float *tri_pos, int n, int n_pow2, const float *lo, const float *hi,
                             unsigned long long *keys) {
@@ -891,7 +893,7 @@ extern "C" int rt_build_accel(rt_ctx *ctx) {
     std::vector<int32_t> roots(ctx->meshes.size() + 1, 0);
     if (e == hipSuccess) e = hipMemcpy(roots.data(), d_root, roots.size() * sizeof(int32_t), hipMemcpyDeviceToHost);
     cleanup();
-    if (e != hipSuccess) return fail(ctx, RT_ERR_HIP, std::string("LBVH build: ") + hipGetErrorString(e));
+    if (e != hipSuccess) return fail(ctx, RT_ERR_HIP, std::string("tree build: ") + hipGetErrorString(e));
     (void)hipEventElapsedTime(&ctx->last_build_ms, ctx->ev0, ctx->ev1);
     ctx->bvh_max_depth = 0;
     for (size_t i = 0; i < ctx->meshes.size(); i++) {
@@ -899,7 +901,7 @@ extern "C" int rt_build_accel(rt_ctx *ctx) {
         ctx->bvh_max_depth = std::max(ctx->bvh_max_depth, roots[i]);
     }
     if (ctx->bvh_max_depth > kStackDepth)
-        return fail(ctx, RT_ERR_LIMIT, "LBVH height " + std::to_string(ctx->bvh_max_depth) + " exceeds the traversal stack (" +
+        return fail(ctx, RT_ERR_LIMIT, "tree height " + std::to_string(ctx->bvh_max_depth) + " exceeds the traversal stack (" +
                                            std::to_string(kStackDepth) + ")");
     ctx->built = true;
     return RT_OK;
