@@ -985,7 +985,7 @@ extern "C" int rt_render_shard_device(rt_ctx *ctx, const rt_render_params *p, fl
                 hipEventElapsedTime(&t.ms[v], t.ev[v][0], t.ev[v][1]) == hipSuccess)
                 t.have[v] = true;
         (void)hipGetLastError();  // hipErrorNotReady from the query is not an error of this call
-        if (t.choice < 0 && t.have[0] && t.have[1]) t.choice = t.ms[1] < 0.95f * t.ms[0] ? 1 : 0;  // the first launch ran cold
+        if (t.choice < 0 && t.have[0] && t.have[1]) t.choice = t.ms[1] < 0.98f * t.ms[0] ? 1 : 0;  // (a tie goes to the simpler kernel)
         if (t.choice >= 0) split = t.choice == 1;
         else if (!t.recorded[0]) { split = false; measure = 0; }
         else if (!t.recorded[1]) { split = true; measure = 1; }
