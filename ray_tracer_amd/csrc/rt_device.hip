@@ -46,6 +46,7 @@ constexpr int render_waves(int features, bool count) {
 // k_render_split holds a round's radiance in LDS as well: with the larger parking area of the variants with
 // secondary rays only four blocks fit a compute unit
 constexpr int split_waves(int features, bool count) { return (features & F_SECONDARY) ? 4 : render_waves(features, count); }
+constexpr int kRenderVariants = 3;  // k_render, k_render_split<PH = 1>, k_render_split<PH = 2>
 constexpr int kWavesPerBlock = kBlock / 64;
 constexpr int kStackWords = 3 * kStackDepth;
 // The packet traversal keeps ONE stack per wave: entries of (node, 64-bit lane mask), three LDS
@@ -313,12 +314,13 @@ __global__ __launch_bounds__(kBlock, render_waves(F, COUNT)) void k_render(DevSc
     flush_work(wk, counters, COUNT);
 }
 
-// The same frame with the taps of a pixel spread over the four waves of a block: block b renders the
-// 8x8 quadrant b & 3 of local tile b >> 2; in rounds of kRoundTaps taps, wave w traces its quarter of
-// the round's taps for all 64 pixels and leaves each tap's radiance in LDS; wave 0 then adds them to
-// the pixel sums in tap order, exactly as the one-lane-per-pixel kernel does.  With many taps per
-// pixel this bounds the time of the most expensive block to a quarter, which is what limits frames
-// whose cost is concentrated in few pixels.
+// The same frame with the taps of a pixel spread over the waves of a block.  PH = 1: block b renders the
+// 8x8 quadrant b & 3 of local tile b >> 2; in rounds of kRoundTaps taps, wave w traces its quarter of the
+// round's taps for all 64 pixels and leaves each tap's radiance in LDS; wave 0 then adds them to the pixel
+// sums in tap order, exactly as the one-lane-per-pixel kernel does.  PH = 2: a block has half a quadrant
+// (8x4 pixels), and the two halves of a wave trace different taps of the same 32 pixels, so a round's eight
+// taps are traced in one step.  This bounds the time of the most expensive block to a quarter (an eighth),
+// which is what limits frames whose cost is concentrated in few pixels and launches of few tiles.
 constexpr int kRoundTaps = 8;
 struct TapSlice {  // a trace_loop source: taps [k, k_end) of one pixel
     Camera cam;
@@ -326,7 +328,8 @@ struct TapSlice {  // a trace_loop source: taps [k, k_end) of one pixel
     int col, row;           // GRID: k = row * grid_m + col
     const float *grid_off;  // GRID: the block's table of grid_offset(a, grid_m, cam.s)
     float wt;
-    float *slots;  // this lane's column of the LDS array [kRoundTaps][3][64]
+    float *slots;  // this lane's column of the LDS array [kRoundTaps][3][pixels of the block]
+    int stride;    // pixels of the block
     __device__ bool next(v3 &ro, v3 &rd) {
         if (k >= k_end) return false;
         ro = V3(0, 0, 0);
@@ -341,50 +344,56 @@ struct TapSlice {  // a trace_loop source: taps [k, k_end) of one pixel
         return true;
     }
     __device__ void done(v3 r) {
-        float *p = slots + (k - 1 - base) * 3 * 64;
-        p[0] = r.x; p[64] = r.y; p[128] = r.z;
+        float *p = slots + (k - 1 - base) * 3 * stride;
+        p[0] = r.x; p[stride] = r.y; p[2 * stride] = r.z;
     }
     __device__ rt_hit_record *first_hit() { return nullptr; }
 };
 
-template <int F, bool COUNT>
+template <int F, bool COUNT, int PH>
 __global__ __launch_bounds__(kBlock, split_waves(F, COUNT)) void k_render_split(DevScene S, RenderArgs a, float *rgb_tiles,
                                                                                  uint8_t *rgb8_tiles, unsigned long long *counters) {
+    constexpr int PX = 64 / PH;  // pixels of a block
     RT_WAVE_STACK(stk, F);
-    __shared__ float tap_lds[kRoundTaps * 3 * 64];
+    __shared__ float tap_lds[kRoundTaps * 3 * PX];
     __shared__ float s_grid_off[kMaxGrid];
     if (threadIdx.x < kMaxGrid) s_grid_off[threadIdx.x] = (int)threadIdx.x < a.grid_m ? grid_offset(threadIdx.x, a.grid_m, a.cam.s) : 0.0f;
     __syncthreads();
-    int local = blockIdx.x >> 2, quad = blockIdx.x & 3;
-    int tile = local * a.world_size + a.rank;
-    int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    int px = (quad & 1) * 8 + (lane & 7), py = (quad >> 1) * 8 + (lane >> 3);
-    int i = (tile % a.tiles_x) * RT_TILE_W + px, j = (tile / a.tiles_x) * RT_TILE_H + py;
+    const int local = blockIdx.x / (4 * PH), part = blockIdx.x % (4 * PH);
+    const int quad = part / PH, sub = part % PH;
+    const int tile = local * a.world_size + a.rank;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int pl = lane % PX, phase = lane / PX;  // this lane's pixel of the block and which of the wave's PH taps it traces
+    const int q = sub * PX + pl;                  // pixel of the quadrant, row-major
+    const int px = (quad & 1) * 8 + (q & 7), py = (quad >> 1) * 8 + (q >> 3);
+    const int i = (tile % a.tiles_x) * RT_TILE_W + px, j = (tile / a.tiles_x) * RT_TILE_H + py;
     Work wk;
     work_zero(wk);
     bool inside = tile < a.tiles_total && i < a.width && j < a.height;
     const int taps = taps_of(a.mode, a.grid_m);
+    const int slot = wave * PH + phase;  // one of the block's 4 * PH tap slots
     v3 color = V3(0, 0, 0);
     for (int base = 0; base < taps; base += kRoundTaps) {
-        int n = taps - base < kRoundTaps ? taps - base : kRoundTaps, chunk = (n + 3) >> 2;
+        int n = taps - base < kRoundTaps ? taps - base : kRoundTaps, chunk = (n + 4 * PH - 1) / (4 * PH);
         TapSlice src;
         src.cam = a.cam; src.mode = a.mode; src.grid_m = a.grid_m; src.i = i; src.j = j; src.base = base; src.wt = 1.0f;
-        src.k = base + wave * chunk;
+        src.k = base + (slot * chunk < n ? slot * chunk : n);
+        src.k_end = base + ((slot + 1) * chunk < n ? (slot + 1) * chunk : n);
         src.col = src.k % a.grid_m; src.row = src.k / a.grid_m; src.grid_off = s_grid_off;  // (one division per round, not per tap)
-        src.k_end = base + ((wave + 1) * chunk < n ? (wave + 1) * chunk : n);
-        src.slots = tap_lds + lane;
+        src.slots = tap_lds + pl;
+        src.stride = PX;
         if (inside && src.k < src.k_end) trace_loop<F, COUNT>(S, a.max_depth, a.accel, stk, wk, src);
         __syncthreads();
-        if (wave == 0 && inside) {
+        if (wave == 0 && phase == 0 && inside) {
             for (int t = 0; t < n; t++) {
-                const float *p = tap_lds + t * 3 * 64 + lane;
-                v3 r = V3(p[0], p[64], p[128]);
+                const float *p = tap_lds + t * 3 * PX + pl;
+                v3 r = V3(p[0], p[PX], p[2 * PX]);
                 color = a.mode == RT_MODE_REF_1SPP ? r : color + r * tap_weight(a.mode, base + t);
             }
         }
         __syncthreads();
     }
-    if (wave == 0) {
+    if (wave == 0 && phase == 0) {
         if (a.mode != RT_MODE_REF_1SPP) color = color / (a.mode == RT_MODE_REF_AA9 ? 16.f : (float)taps);
         size_t p = ((size_t)local * (RT_TILE_W * RT_TILE_H) + (size_t)py * RT_TILE_W + px) * 3;
         if (rgb_tiles) { rgb_tiles[p] = color.x; rgb_tiles[p + 1] = color.y; rgb_tiles[p + 2] = color.z; }
@@ -483,16 +492,18 @@ struct rt_ctx {
     bool split_forced = false;  // RT_SPLIT_MIN_TAPS (tests, tuning) sets the threshold for every scene
     int n_cus = 256;            // compute units of the device
     bool radix_tree = false;    // RT_BUILD=radix: the Morton radix tree instead of the surface-area splits
-    // Which of the two render kernels (0: k_render, 1: k_render_split; same pixels bit for bit) is faster for
-    // the current frame parameters: each is timed once, on the first two launches with these parameters.
+    // Which of the render kernels (0: k_render, 1 and 2: k_render_split with one and two tap phases per wave; same
+    // pixels bit for bit) is fastest for the current frame parameters: each is timed once, on the first launches
+    // with these parameters.
     struct Tune {
         int32_t key[11] = {0};
         bool valid = false;
-        hipEvent_t ev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
-        bool recorded[2] = {false, false}, have[2] = {false, false};
-        float ms[2] = {0, 0};
+        hipEvent_t ev[kRenderVariants][2] = {};
+        bool recorded[kRenderVariants] = {}, have[kRenderVariants] = {};
+        float ms[kRenderVariants] = {};
         int choice = -1;
     } tune;
+    int split_phases = 1;  // RT_SPLIT_PHASES: which split kernel RT_SPLIT_MIN_TAPS selects
     int last_variant = 0;
 };
 
@@ -546,11 +557,12 @@ extern "C" int rt_context_create(int device, rt_ctx **out) {
         return RT_ERR_HIP;
     }
     ctx->stream = ctx->own_stream;
-    for (int v = 0; v < 2; v++)
+    for (int v = 0; v < kRenderVariants; v++)
         for (int k = 0; k < 2; k++)
             if (hipEventCreate(&ctx->tune.ev[v][k]) != hipSuccess) { delete ctx; return RT_ERR_HIP; }
     if (hipDeviceGetAttribute(&ctx->n_cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || ctx->n_cus <= 0) ctx->n_cus = 256;
     if (const char *e = std::getenv("RT_BUILD")) ctx->radix_tree = std::strcmp(e, "radix") == 0;
+    if (const char *e = std::getenv("RT_SPLIT_PHASES")) ctx->split_phases = std::atoi(e) == 2 ? 2 : 1;
     if (const char *e = std::getenv("RT_SPLIT_MIN_TAPS")) { ctx->split_min_taps = std::atoi(e); ctx->split_forced = true; }
     void *c = nullptr;
     if (hipMalloc(&c, (size_t)kCounterStripes * kCounterStride * sizeof(unsigned long long)) != hipSuccess ||
@@ -571,7 +583,7 @@ extern "C" int rt_context_destroy(rt_ctx *ctx) {
     (void)hipFree(ctx->d_counters);
     (void)hipEventDestroy(ctx->ev0);
     (void)hipEventDestroy(ctx->ev1);
-    for (int v = 0; v < 2; v++)
+    for (int v = 0; v < kRenderVariants; v++)
         for (int k = 0; k < 2; k++) (void)hipEventDestroy(ctx->tune.ev[v][k]);
     (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
@@ -960,13 +972,14 @@ extern "C" int rt_render_shard_device(rt_ctx *ctx, const rt_render_params *p, fl
     // A block of k_render runs all taps of its pixels one after the other, and a tile on a mesh takes many times
     // as long as the average tile.  With many taps, or with so few tiles per launch that the launch is no longer
     // than a few such blocks (one rank's share of a frame on several GPUs), that one block decides the frame time
-    // and k_render_split, whose blocks are a quarter as long, is faster in spite of its barriers.  Which one wins
-    // depends on the scene, so both are timed once (first two launches with these parameters; they write the
-    // same pixels) and the faster one is kept; until the timings are in, the rule of thumb below decides.
+    // and k_render_split, whose blocks are a quarter or an eighth as long, is faster in spite of its barriers.
+    // Which one wins depends on the scene, so each is timed once (first launches with these parameters; they
+    // write the same pixels) and the fastest is kept; until the timings are in, the rule of thumb below decides.
     const int taps = taps_of(p->mode, p->grid_m);
     const bool few_tiles = taps >= 2 * kRoundTaps && local_tiles < 16 * 5 * ctx->n_cus;  // under 16 rounds of resident blocks
-    bool split = ctx->split_forced ? taps >= ctx->split_min_taps
-                                   : (ctx->features & F_MESH) && (taps >= ctx->split_min_taps || few_tiles);
+    int variant = 0;
+    if (ctx->split_forced) variant = taps >= ctx->split_min_taps ? ctx->split_phases : 0;
+    else if ((ctx->features & F_MESH) && (taps >= ctx->split_min_taps || few_tiles)) variant = 1;
     int measure = -1;
     if (!ctx->split_forced && !p->count_work && taps >= 4 && (ctx->features & F_MESH)) {
         rt_ctx::Tune &t = ctx->tune;
@@ -977,31 +990,42 @@ extern "C" int rt_render_shard_device(rt_ctx *ctx, const rt_render_params *p, fl
         if (!t.valid || std::memcmp(key, t.key, sizeof key) != 0) {
             std::memcpy(t.key, key, sizeof key);
             t.valid = true;
-            t.recorded[0] = t.recorded[1] = t.have[0] = t.have[1] = false;
+            for (int v = 0; v < kRenderVariants; v++) t.recorded[v] = t.have[v] = false;
             t.choice = -1;
         }
-        for (int v = 0; v < 2 && t.choice < 0; v++)
+        for (int v = 0; v < kRenderVariants && t.choice < 0; v++)
             if (t.recorded[v] && !t.have[v] && hipEventQuery(t.ev[v][1]) == hipSuccess &&
                 hipEventElapsedTime(&t.ms[v], t.ev[v][0], t.ev[v][1]) == hipSuccess)
                 t.have[v] = true;
         (void)hipGetLastError();  // hipErrorNotReady from the query is not an error of this call
-        if (t.choice < 0 && t.have[0] && t.have[1]) t.choice = t.ms[1] < 0.98f * t.ms[0] ? 1 : 0;  // (a tie goes to the simpler kernel)
-        if (t.choice >= 0) split = t.choice == 1;
-        else if (!t.recorded[0]) { split = false; measure = 0; }
-        else if (!t.recorded[1]) { split = true; measure = 1; }
+        // k_render and the plain split kernel first; the finer split is only tried where splitting pays at all
+        // (a tie goes to the simpler kernel)
+        if (t.choice < 0 && t.have[0] && t.have[1]) {
+            if (!(t.ms[1] < 0.98f * t.ms[0])) t.choice = 0;
+            else if (t.have[2]) t.choice = t.ms[2] < 0.98f * t.ms[1] ? 2 : 1;
+        }
+        if (t.choice >= 0) variant = t.choice;
+        else if (!t.recorded[0]) variant = measure = 0;
+        else if (!t.recorded[1]) variant = measure = 1;
+        else if (t.have[0] && t.have[1] && !t.recorded[2]) variant = measure = 2;
+        else if (t.have[0] && t.have[1]) variant = 1;  // waiting for the third timing
     }
-    ctx->last_variant = split ? 1 : 0;
-    render_fn kernel = split ? k_render_split<F_ALL, false> : k_render<F_ALL, false>;
+    ctx->last_variant = variant;
     int f = ctx->features;
-#define RT_PICK(FEATURES) (split ? (render_fn)k_render_split<FEATURES, false> : (render_fn)k_render<FEATURES, false>)
-    if (p->count_work) kernel = split ? (render_fn)k_render_split<F_ALL, true> : (render_fn)k_render<F_ALL, true>;
-    else if ((f & ~F_MESH) == 0) kernel = RT_PICK(F_MESH);
-    else if ((f & ~(F_MESH | F_SECONDARY)) == 0) kernel = RT_PICK(F_MESH | F_SECONDARY);
-    else if ((f & ~(F_QUADRIC | F_SECONDARY)) == 0) kernel = RT_PICK(F_QUADRIC | F_SECONDARY);
-    else if ((f & ~(F_MESH | F_TEXTURE | F_SECONDARY)) == 0) kernel = RT_PICK(F_MESH | F_TEXTURE | F_SECONDARY);
+    render_fn kernel;
+#define RT_PICK(FEATURES, COUNT)                                                              \
+    (variant == 0 ? (render_fn)k_render<FEATURES, COUNT>                                      \
+                  : variant == 1 ? (render_fn)k_render_split<FEATURES, COUNT, 1> : (render_fn)k_render_split<FEATURES, COUNT, 2>)
+    if (p->count_work) kernel = RT_PICK(F_ALL, true);
+    else if ((f & ~F_MESH) == 0) kernel = RT_PICK(F_MESH, false);
+    else if ((f & ~(F_MESH | F_SECONDARY)) == 0) kernel = RT_PICK(F_MESH | F_SECONDARY, false);
+    else if ((f & ~(F_QUADRIC | F_SECONDARY)) == 0) kernel = RT_PICK(F_QUADRIC | F_SECONDARY, false);
+    else if ((f & ~(F_MESH | F_TEXTURE | F_SECONDARY)) == 0) kernel = RT_PICK(F_MESH | F_TEXTURE | F_SECONDARY, false);
+    else kernel = RT_PICK(F_ALL, false);
 #undef RT_PICK
+    const int blocks_per_tile = variant == 0 ? 1 : variant == 1 ? 4 : 8;
     if (measure >= 0) RT_HIP(hipEventRecord(ctx->tune.ev[measure][0], ctx->stream));
-    hipLaunchKernelGGL(kernel, dim3(split ? 4 * local_tiles : local_tiles), dim3(kBlock), 0, ctx->stream, ctx->S, a, d_rgb_tiles,
+    hipLaunchKernelGGL(kernel, dim3(blocks_per_tile * local_tiles), dim3(kBlock), 0, ctx->stream, ctx->S, a, d_rgb_tiles,
                        d_rgb8_tiles, ctx->d_counters);
     RT_HIP(hipGetLastError());
     if (measure >= 0) {

@@ -319,12 +319,15 @@ def test_shadow_query_cull_changes_nothing(kind):
 
 @pytest.mark.parametrize("preset,mode,grid", [("teapot", rt.MODE_GRID, 4), ("analytic", rt.MODE_REF_AA9, 1), ("analytic", rt.MODE_REF_1SPP, 1),
                                               ("textured", rt.MODE_GRID, 3), ("shells", rt.MODE_GRID, 8), ("teapot", rt.MODE_GRID, 7)])
-def test_tap_splitting_kernel_is_bit_identical(preset, mode, grid, host_scene, monkeypatch):
-    """k_render_split (a pixel's taps spread over the four waves of a block, summed in tap order by one
-    wave) against k_render (one lane per pixel): the same frame bit for bit, for tap counts that do and
-    do not divide by four, fill less than one round (8 taps) or need several."""
+@pytest.mark.parametrize("phases", ["1", "2"])
+def test_tap_splitting_kernel_is_bit_identical(preset, mode, grid, phases, host_scene, monkeypatch):
+    """k_render_split (a pixel's taps spread over the four waves of a block -- with two phases also over the
+    halves of each wave -- and summed in tap order by one wave) against k_render (one lane per pixel): the same
+    frame bit for bit, for tap counts that do and do not divide by four, fill less than one round (8 taps) or
+    need several."""
     w, h = 88, 50  # not a multiple of the tile size
     frames = []
+    monkeypatch.setenv("RT_SPLIT_PHASES", phases)
     for min_taps in ("1", "100000"):
         monkeypatch.setenv("RT_SPLIT_MIN_TAPS", min_taps)
         ctx = rt.Context(0)
@@ -409,16 +412,17 @@ def test_tall_tree_equals_brute_force_on_gpu(builder, monkeypatch):
 
 def test_render_kernel_choice_by_timing_keeps_the_pixels(gpu_ctx):
     """With new frame parameters the first launch runs the one-lane-per-pixel kernel, the second the kernel that
-    spreads a pixel's taps over a block's waves, and from the third on the one that was faster: three frames,
-    two kernels, the same bytes."""
+    spreads a pixel's taps over a block's waves, a third the finer split if the plain one paid, and then the
+    fastest is kept: six frames, two or three kernels, the same bytes."""
     if os.environ.get("RT_SPLIT_MIN_TAPS"):
         pytest.skip("the environment fixes the kernel choice")
     ctx = gpu_ctx("teapot")
     frames, variants = [], []
-    for _ in range(4):
+    for _ in range(6):
         frames.append(ctx.render(333, 177, fov=77.0, mode=rt.MODE_GRID, grid_m=3))
         variants.append(ctx.counters().render_variant)
-    assert variants[:2] == [0, 1] and variants[2] in (0, 1) and variants[3] == variants[2]
+    assert variants[:2] == [0, 1] and variants[2] in (0, 2) and variants[3] in (0, 1, 2)
+    assert variants[3] == variants[4] == variants[5]
     for rgb, rgb8 in frames[1:]:
         assert np.array_equal(rgb8, frames[0][1]) and np.array_equal(rgb, frames[0][0], equal_nan=True)
 
