@@ -54,7 +54,6 @@ struct Twin {
     std::vector<std::vector<u4>> texels;
     std::vector<float> srgb_lut;
     int bvh_max_depth = 0;
-    std::vector<std::vector<int32_t>> kids;  // per mesh: c0[n-1] then c1[n-1]
     Work total{};
 };
 
@@ -225,8 +224,6 @@ int twin_build_accel(void *h) {
         if (!(builder && std::strcmp(builder, "radix") == 0)) root = sah_children(n, leaf_box, c0, c1);
         t->build[mi].root = root;
         t->meshes[mi].root = root;
-        t->kids.resize(t->meshes.size());
-        t->kids[mi] = c0; t->kids[mi].insert(t->kids[mi].end(), c1.begin(), c1.end());
         for (int pass = 1; pass <= 4096; pass++) {
             int left = 0;
             for (int i = 0; i < n - 1; i++)
@@ -295,13 +292,6 @@ void twin_render(void *h, const rt_render_params *p, int x0, int y0, int x1, int
             for (int k = 0; k < 10; k++) acc[k] += vals[k];
         }
     if (counters) for (int k = 0; k < 10; k++) counters[k] += acc[k];
-}
-
-int twin_copy_children(void *h, int mesh, int32_t *out) {
-    Twin *t = static_cast<Twin *>(h);
-    if (mesh >= (int)t->kids.size()) return 0;
-    std::memcpy(out, t->kids[mesh].data(), t->kids[mesh].size() * sizeof(int32_t));
-    return (int)t->kids[mesh].size();
 }
 
 // number of references (leaves) of a mesh's tree
