@@ -174,7 +174,7 @@ def main():
                        "parallelism": f"tiles{world}", "rays_per_frame": rays_total / args.steps,
                        "bvh_height": c.bvh_max_depth, "lbvh_build_ms": c.last_build_ms,
                        "tree_build": "radix" if os.environ.get("RT_BUILD") == "radix" else "binned surface-area splits",
-                       "render_kernel": ("k_render", "k_render_split<1>", "k_render_split<2>")[c.render_variant]},
+                       "render_kernel": ("k_render", "k_render_split<1>", "k_render_split<2>", "k_render_hybrid")[c.render_variant]},
             "roofline": {"bound": "valu", "achieved": achieved_tflops, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved_tflops / PEAK_FP32_TFLOPS, "traffic": traffic,
                          "kernel": "k_render", "kernel_ms": kernel_ms,

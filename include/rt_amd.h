@@ -185,8 +185,9 @@ typedef struct {
     float last_build_ms;  /* device time of the last rt_build_accel                */
     int32_t bvh_max_depth;
     int32_t render_variant; /* kernel of the last render launch: 0 one lane per pixel; 1, 2 a pixel's taps spread
-                               over the waves of a block, with one or two taps per wave at a time (same
-                               pixels; the fastest is found by timing each once) */
+                               over the waves of a block, with one or two taps per wave at a time; 3 either way
+                               per tile, by the tile's time in the frame before (same pixels from all of them;
+                               the fastest is found by timing each once) */
 } rt_counters;
 
 /* Create / destroy a context on GPU `device` (a HIP device ordinal). */

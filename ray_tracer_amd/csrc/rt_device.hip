@@ -46,7 +46,7 @@ constexpr int render_waves(int features, bool count) {
 // k_render_split holds a round's radiance in LDS as well: with the larger parking area of the variants with
 // secondary rays only four blocks fit a compute unit
 constexpr int split_waves(int features, bool count) { return (features & F_SECONDARY) ? 4 : render_waves(features, count); }
-constexpr int kRenderVariants = 3;  // k_render, k_render_split<PH = 1>, k_render_split<PH = 2>
+constexpr int kRenderVariants = 4;  // k_render, k_render_split<PH = 1>, k_render_split<PH = 2>, k_render_hybrid
 constexpr int kWavesPerBlock = kBlock / 64;
 constexpr int kStackWords = 3 * kStackDepth;
 // The packet traversal keeps ONE stack per wave: entries of (node, 64-bit lane mask), three LDS
@@ -287,23 +287,18 @@ __global__ void k_octant_variants(BvhNode *nodes, int n) {
     nodes[(size_t)o * n + i] = lbvh_octant_variant(nodes[i], o);
 }
 
+// One 16x16 tile by one block: each wave an 8x8 quadrant, each lane a pixel with all its taps.
 template <int F, bool COUNT>
-__global__ __launch_bounds__(kBlock, render_waves(F, COUNT)) void k_render(DevScene S, RenderArgs a, float *rgb_tiles, uint8_t *rgb8_tiles,
-                                                   unsigned long long *counters) {
-    RT_WAVE_STACK(stk, F);
-    int tile = blockIdx.x * a.world_size + a.rank;
+__device__ __forceinline__ void render_tile(const DevScene &S, const RenderArgs &a, int local, WaveStack &stk, const float *grid_off,
+                                            float *rgb_tiles, uint8_t *rgb8_tiles, Work &wk) {
+    int tile = local * a.world_size + a.rank;
     int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     int px = (wave & 1) * 8 + (lane & 7), py = (wave >> 1) * 8 + (lane >> 3);
     int i = (tile % a.tiles_x) * RT_TILE_W + px, j = (tile / a.tiles_x) * RT_TILE_H + py;
-    Work wk;
-    work_zero(wk);
     v3 color = V3(0, 0, 0);
     bool inside = tile < a.tiles_total && i < a.width && j < a.height;
-    __shared__ float s_grid_off[kMaxGrid];
-    if (threadIdx.x < kMaxGrid) s_grid_off[threadIdx.x] = (int)threadIdx.x < a.grid_m ? grid_offset(threadIdx.x, a.grid_m, a.cam.s) : 0.0f;
-    __syncthreads();
-    if (inside) color = render_pixel<F, COUNT>(S, a.cam, a.mode, a.grid_m, a.max_depth, a.accel, i, j, s_grid_off, stk, wk);
-    size_t p = ((size_t)blockIdx.x * (RT_TILE_W * RT_TILE_H) + (size_t)py * RT_TILE_W + px) * 3;
+    if (inside) color = render_pixel<F, COUNT>(S, a.cam, a.mode, a.grid_m, a.max_depth, a.accel, i, j, grid_off, stk, wk);
+    size_t p = ((size_t)local * (RT_TILE_W * RT_TILE_H) + (size_t)py * RT_TILE_W + px) * 3;
     if (rgb_tiles) { rgb_tiles[p] = color.x; rgb_tiles[p + 1] = color.y; rgb_tiles[p + 2] = color.z; }
     if (rgb8_tiles) {
         v3 t = tone_map(color);
@@ -311,6 +306,21 @@ __global__ __launch_bounds__(kBlock, render_waves(F, COUNT)) void k_render(DevSc
         rgb8_tiles[p + 1] = inside ? quantise(t.y) : 0;
         rgb8_tiles[p + 2] = inside ? quantise(t.z) : 0;
     }
+}
+__device__ __forceinline__ void fill_grid_table(float *s_grid_off, const RenderArgs &a) {
+    if (threadIdx.x < kMaxGrid) s_grid_off[threadIdx.x] = (int)threadIdx.x < a.grid_m ? grid_offset(threadIdx.x, a.grid_m, a.cam.s) : 0.0f;
+    __syncthreads();
+}
+
+template <int F, bool COUNT>
+__global__ __launch_bounds__(kBlock, render_waves(F, COUNT)) void k_render(DevScene S, RenderArgs a, float *rgb_tiles, uint8_t *rgb8_tiles,
+                                                   unsigned long long *counters) {
+    RT_WAVE_STACK(stk, F);
+    __shared__ float s_grid_off[kMaxGrid];
+    fill_grid_table(s_grid_off, a);
+    Work wk;
+    work_zero(wk);
+    render_tile<F, COUNT>(S, a, blockIdx.x, stk, s_grid_off, rgb_tiles, rgb8_tiles, wk);
     flush_work(wk, counters, COUNT);
 }
 
@@ -350,16 +360,11 @@ struct TapSlice {  // a trace_loop source: taps [k, k_end) of one pixel
     __device__ rt_hit_record *first_hit() { return nullptr; }
 };
 
+// Part `part` (of 4 * PH) of local tile `local` by one block; tap_lds: kRoundTaps * 3 * (64 / PH) floats of LDS.
 template <int F, bool COUNT, int PH>
-__global__ __launch_bounds__(kBlock, split_waves(F, COUNT)) void k_render_split(DevScene S, RenderArgs a, float *rgb_tiles,
-                                                                                 uint8_t *rgb8_tiles, unsigned long long *counters) {
+__device__ __forceinline__ void render_tile_part(const DevScene &S, const RenderArgs &a, int local, int part, WaveStack &stk,
+                                                 const float *grid_off, float *tap_lds, float *rgb_tiles, uint8_t *rgb8_tiles, Work &wk) {
     constexpr int PX = 64 / PH;  // pixels of a block
-    RT_WAVE_STACK(stk, F);
-    __shared__ float tap_lds[kRoundTaps * 3 * PX];
-    __shared__ float s_grid_off[kMaxGrid];
-    if (threadIdx.x < kMaxGrid) s_grid_off[threadIdx.x] = (int)threadIdx.x < a.grid_m ? grid_offset(threadIdx.x, a.grid_m, a.cam.s) : 0.0f;
-    __syncthreads();
-    const int local = blockIdx.x / (4 * PH), part = blockIdx.x % (4 * PH);
     const int quad = part / PH, sub = part % PH;
     const int tile = local * a.world_size + a.rank;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -367,8 +372,6 @@ __global__ __launch_bounds__(kBlock, split_waves(F, COUNT)) void k_render_split(
     const int q = sub * PX + pl;                  // pixel of the quadrant, row-major
     const int px = (quad & 1) * 8 + (q & 7), py = (quad >> 1) * 8 + (q >> 3);
     const int i = (tile % a.tiles_x) * RT_TILE_W + px, j = (tile / a.tiles_x) * RT_TILE_H + py;
-    Work wk;
-    work_zero(wk);
     bool inside = tile < a.tiles_total && i < a.width && j < a.height;
     const int taps = taps_of(a.mode, a.grid_m);
     const int slot = wave * PH + phase;  // one of the block's 4 * PH tap slots
@@ -379,7 +382,7 @@ __global__ __launch_bounds__(kBlock, split_waves(F, COUNT)) void k_render_split(
         src.cam = a.cam; src.mode = a.mode; src.grid_m = a.grid_m; src.i = i; src.j = j; src.base = base; src.wt = 1.0f;
         src.k = base + (slot * chunk < n ? slot * chunk : n);
         src.k_end = base + ((slot + 1) * chunk < n ? (slot + 1) * chunk : n);
-        src.col = src.k % a.grid_m; src.row = src.k / a.grid_m; src.grid_off = s_grid_off;  // (one division per round, not per tap)
+        src.col = src.k % a.grid_m; src.row = src.k / a.grid_m; src.grid_off = grid_off;  // (one division per round, not per tap)
         src.slots = tap_lds + pl;
         src.stride = PX;
         if (inside && src.k < src.k_end) trace_loop<F, COUNT>(S, a.max_depth, a.accel, stk, wk, src);
@@ -404,7 +407,54 @@ __global__ __launch_bounds__(kBlock, split_waves(F, COUNT)) void k_render_split(
             rgb8_tiles[p + 2] = inside ? quantise(t.z) : 0;
         }
     }
+}
+
+template <int F, bool COUNT, int PH>
+__global__ __launch_bounds__(kBlock, split_waves(F, COUNT)) void k_render_split(DevScene S, RenderArgs a, float *rgb_tiles,
+                                                                                 uint8_t *rgb8_tiles, unsigned long long *counters) {
+    RT_WAVE_STACK(stk, F);
+    __shared__ float tap_lds[kRoundTaps * 3 * (64 / PH)];
+    __shared__ float s_grid_off[kMaxGrid];
+    fill_grid_table(s_grid_off, a);
+    Work wk;
+    work_zero(wk);
+    render_tile_part<F, COUNT, PH>(S, a, blockIdx.x / (4 * PH), blockIdx.x % (4 * PH), stk, s_grid_off, tap_lds, rgb_tiles, rgb8_tiles, wk);
     flush_work(wk, counters, COUNT);
+}
+
+// Both ways in one launch, chosen per tile: four blocks per tile; a tile that took long in the previous frame
+// (cost_in, in ticks of the 100 MHz clock, above `threshold`) is rendered by all four, a quadrant each with
+// the taps spread over the waves; any other tile by one of its blocks alone, the other three leave at once.
+// The heavy tiles then no longer decide the length of a short launch (one rank's share of a frame), and the
+// light ones keep the cheaper kernel.  One block of every tile leaves the tile's time for the next frame in
+// cost_out (another array than cost_in: the four blocks of a tile must read the same value).
+struct TileCosts { const uint32_t *cost_in; uint32_t *cost_out; uint32_t threshold; };
+template <int F>
+__global__ __launch_bounds__(kBlock, split_waves(F, false)) void k_render_hybrid(DevScene S, RenderArgs a, float *rgb_tiles,
+                                                                                  uint8_t *rgb8_tiles, unsigned long long *counters,
+                                                                                  TileCosts tc) {
+    const int local = blockIdx.x >> 2, quad = blockIdx.x & 3;
+    const bool heavy = tc.cost_in[local] > tc.threshold;  // the same for the tile's four blocks
+    // Which of the four blocks takes a light tile is scattered by a hash of the tile: blocks are handed to the
+    // XCDs and their compute units in turn, and a regular pattern of working and leaving blocks keeps most of
+    // them idle (measured: 12.7 ms with always the first block, 12.1 ms with a rotation, 3.3 ms scattered).
+    const int worker = (int)(((uint32_t)local * 2654435761u) >> 13) & 3;
+    if (!heavy && quad != worker) return;
+    const unsigned long long t0 = wall_clock64();
+    RT_WAVE_STACK(stk, F);
+    __shared__ float tap_lds[kRoundTaps * 3 * 64];
+    __shared__ float s_grid_off[kMaxGrid];
+    fill_grid_table(s_grid_off, a);
+    Work wk;
+    work_zero(wk);
+    if (heavy) render_tile_part<F, false, 1>(S, a, local, quad, stk, s_grid_off, tap_lds, rgb_tiles, rgb8_tiles, wk);
+    else render_tile<F, false>(S, a, local, stk, s_grid_off, rgb_tiles, rgb8_tiles, wk);
+    flush_work(wk, counters, false);
+    __syncthreads();
+    if (threadIdx.x == 0 && quad == worker) {
+        unsigned long long dt = (wall_clock64() - t0) * (heavy ? 4ull : 1ull);  // a quadrant's time stands for a quarter of the tile's
+        tc.cost_out[local] = dt > 0xffffffffull ? 0xffffffffu : (uint32_t)dt;
+    }
 }
 
 // shards[r][local_tile][16][16][3] -> frame[y][x][3]; first_rank/n_ranks select which shards exist
@@ -504,6 +554,11 @@ struct rt_ctx {
         int choice = -1;
     } tune;
     int split_phases = 1;  // RT_SPLIT_PHASES: which split kernel RT_SPLIT_MIN_TAPS selects
+    // k_render_hybrid: the time every tile took in the last frame, two arrays used in turn (read one, write the other)
+    uint32_t *d_tile_cost[2] = {nullptr, nullptr};
+    int tile_cost_cap = 0, tile_cost_turn = 0, hybrid_runs = 0;
+    int forced_variant = -1;          // RT_RENDER_VARIANT: this kernel for every frame (tests)
+    long long forced_threshold = -1;  // RT_HYBRID_THRESHOLD: ticks of 10 ns above which a tile counts as heavy (tests)
     int last_variant = 0;
 };
 
@@ -563,6 +618,8 @@ extern "C" int rt_context_create(int device, rt_ctx **out) {
     if (hipDeviceGetAttribute(&ctx->n_cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || ctx->n_cus <= 0) ctx->n_cus = 256;
     if (const char *e = std::getenv("RT_BUILD")) ctx->radix_tree = std::strcmp(e, "radix") == 0;
     if (const char *e = std::getenv("RT_SPLIT_PHASES")) ctx->split_phases = std::atoi(e) == 2 ? 2 : 1;
+    if (const char *e = std::getenv("RT_RENDER_VARIANT")) ctx->forced_variant = std::max(0, std::min(kRenderVariants - 1, std::atoi(e)));
+    if (const char *e = std::getenv("RT_HYBRID_THRESHOLD")) ctx->forced_threshold = std::atoll(e);
     if (const char *e = std::getenv("RT_SPLIT_MIN_TAPS")) { ctx->split_min_taps = std::atoi(e); ctx->split_forced = true; }
     void *c = nullptr;
     if (hipMalloc(&c, (size_t)kCounterStripes * kCounterStride * sizeof(unsigned long long)) != hipSuccess ||
@@ -581,6 +638,8 @@ extern "C" int rt_context_destroy(rt_ctx *ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     free_scene(ctx);
     (void)hipFree(ctx->d_counters);
+    (void)hipFree(ctx->d_tile_cost[0]);
+    (void)hipFree(ctx->d_tile_cost[1]);
     (void)hipEventDestroy(ctx->ev0);
     (void)hipEventDestroy(ctx->ev1);
     for (int v = 0; v < kRenderVariants; v++)
@@ -978,10 +1037,14 @@ extern "C" int rt_render_shard_device(rt_ctx *ctx, const rt_render_params *p, fl
     const int taps = taps_of(p->mode, p->grid_m);
     const bool few_tiles = taps >= 2 * kRoundTaps && local_tiles < 16 * 5 * ctx->n_cus;  // under 16 rounds of resident blocks
     int variant = 0;
-    if (ctx->split_forced) variant = taps >= ctx->split_min_taps ? ctx->split_phases : 0;
+    const bool forced = ctx->split_forced || ctx->forced_variant >= 0;
+    if (ctx->forced_variant >= 0) variant = ctx->forced_variant;
+    else if (ctx->split_forced) variant = taps >= ctx->split_min_taps ? ctx->split_phases : 0;
     else if ((ctx->features & F_MESH) && (taps >= ctx->split_min_taps || few_tiles)) variant = 1;
     int measure = -1;
-    if (!ctx->split_forced && !p->count_work && taps >= 4 && (ctx->features & F_MESH)) {
+    uint32_t threshold = ctx->forced_threshold >= 0 ? (uint32_t)std::min<long long>(ctx->forced_threshold, 0xffffffffll) : 20000u;
+    bool new_key = false;
+    if (!forced && !p->count_work && taps >= 4 && (ctx->features & F_MESH)) {
         rt_ctx::Tune &t = ctx->tune;
         int32_t fov_bits;
         std::memcpy(&fov_bits, &p->fov, sizeof fov_bits);
@@ -992,41 +1055,82 @@ extern "C" int rt_render_shard_device(rt_ctx *ctx, const rt_render_params *p, fl
             t.valid = true;
             for (int v = 0; v < kRenderVariants; v++) t.recorded[v] = t.have[v] = false;
             t.choice = -1;
+            new_key = true;
         }
         for (int v = 0; v < kRenderVariants && t.choice < 0; v++)
             if (t.recorded[v] && !t.have[v] && hipEventQuery(t.ev[v][1]) == hipSuccess &&
                 hipEventElapsedTime(&t.ms[v], t.ev[v][0], t.ev[v][1]) == hipSuccess)
                 t.have[v] = true;
         (void)hipGetLastError();  // hipErrorNotReady from the query is not an error of this call
-        // k_render and the plain split kernel first; the finer split is only tried where splitting pays at all
-        // (a tie goes to the simpler kernel)
-        if (t.choice < 0 && t.have[0] && t.have[1]) {
-            if (!(t.ms[1] < 0.98f * t.ms[0])) t.choice = 0;
-            else if (t.have[2]) t.choice = t.ms[2] < 0.98f * t.ms[1] ? 2 : 1;
+        // k_render and the plain split kernel first.  Where splitting pays, the finer split is tried as well; where
+        // it pays or nearly does (the longest blocks matter), the per-tile choice, which learns the tiles' times in
+        // its first launch, so that its second one is timed.  A tie goes to the simpler kernel.
+        const bool both = t.have[0] && t.have[1];
+        const bool pays = both && t.ms[1] < 0.98f * t.ms[0], near = both && t.ms[1] < 1.1f * t.ms[0];
+        if (t.choice < 0 && both && (!pays || t.have[2]) && (!near || t.have[3])) {
+            t.choice = 0;
+            for (int v = 1; v < kRenderVariants; v++)
+                if (t.have[v] && t.ms[v] < 0.98f * t.ms[t.choice]) t.choice = v;
         }
+        if (both)  // a tile is heavy when it takes 1.5 times the average tile's share of a launch
+            threshold = (uint32_t)std::min(4.0e9, 1.5 * std::min(t.ms[0], t.ms[1]) * 5.0 * ctx->n_cus / local_tiles * 1.0e5);
         if (t.choice >= 0) variant = t.choice;
         else if (!t.recorded[0]) variant = measure = 0;
         else if (!t.recorded[1]) variant = measure = 1;
-        else if (t.have[0] && t.have[1] && !t.recorded[2]) variant = measure = 2;
-        else if (t.have[0] && t.have[1]) variant = 1;  // waiting for the third timing
+        else if (pays && !t.recorded[2]) variant = measure = 2;
+        else if (near && ctx->hybrid_runs == 0) variant = 3;
+        else if (near && !t.recorded[3]) variant = measure = 3;
+        else if (pays) variant = 1;  // waiting for the last timings
     }
+    if (ctx->forced_threshold >= 0) threshold = (uint32_t)std::min<long long>(ctx->forced_threshold, 0xffffffffll);
+    if (p->count_work) variant = 0;  // (the counting instantiation exists for k_render and the split kernels; any gives the same counts)
     ctx->last_variant = variant;
     int f = ctx->features;
     render_fn kernel;
 #define RT_PICK(FEATURES, COUNT)                                                              \
     (variant == 0 ? (render_fn)k_render<FEATURES, COUNT>                                      \
                   : variant == 1 ? (render_fn)k_render_split<FEATURES, COUNT, 1> : (render_fn)k_render_split<FEATURES, COUNT, 2>)
-    if (p->count_work) kernel = RT_PICK(F_ALL, true);
+    if (p->count_work) kernel = (render_fn)k_render<F_ALL, true>;
     else if ((f & ~F_MESH) == 0) kernel = RT_PICK(F_MESH, false);
     else if ((f & ~(F_MESH | F_SECONDARY)) == 0) kernel = RT_PICK(F_MESH | F_SECONDARY, false);
     else if ((f & ~(F_QUADRIC | F_SECONDARY)) == 0) kernel = RT_PICK(F_QUADRIC | F_SECONDARY, false);
     else if ((f & ~(F_MESH | F_TEXTURE | F_SECONDARY)) == 0) kernel = RT_PICK(F_MESH | F_TEXTURE | F_SECONDARY, false);
     else kernel = RT_PICK(F_ALL, false);
 #undef RT_PICK
-    const int blocks_per_tile = variant == 0 ? 1 : variant == 1 ? 4 : 8;
+    const int blocks_per_tile = variant == 0 ? 1 : variant == 2 ? 8 : 4;
+    TileCosts tc = {nullptr, nullptr, threshold};
+    if (variant == 3) {
+        if (local_tiles > ctx->tile_cost_cap) {
+            for (int k = 0; k < 2; k++) {
+                RT_HIP(hipStreamSynchronize(ctx->stream));
+                (void)hipFree(ctx->d_tile_cost[k]);
+                ctx->d_tile_cost[k] = nullptr;
+                RT_HIP(hipMalloc((void **)&ctx->d_tile_cost[k], (size_t)local_tiles * sizeof(uint32_t)));
+            }
+            ctx->tile_cost_cap = local_tiles;
+            new_key = true;
+        }
+        if (new_key || ctx->hybrid_runs == 0)  // nothing known about these tiles: all heavy in the first launch (the safe side for a short launch)
+            RT_HIP(hipMemsetAsync(ctx->d_tile_cost[ctx->tile_cost_turn], 0xff, (size_t)local_tiles * sizeof(uint32_t), ctx->stream));
+        tc.cost_in = ctx->d_tile_cost[ctx->tile_cost_turn];
+        tc.cost_out = ctx->d_tile_cost[ctx->tile_cost_turn ^ 1];
+        ctx->tile_cost_turn ^= 1;
+        ctx->hybrid_runs++;
+    }
+    if (new_key && variant != 3) ctx->hybrid_runs = 0;
     if (measure >= 0) RT_HIP(hipEventRecord(ctx->tune.ev[measure][0], ctx->stream));
-    hipLaunchKernelGGL(kernel, dim3(blocks_per_tile * local_tiles), dim3(kBlock), 0, ctx->stream, ctx->S, a, d_rgb_tiles,
-                       d_rgb8_tiles, ctx->d_counters);
+    if (variant == 3) {
+        typedef void (*hybrid_fn)(DevScene, RenderArgs, float *, uint8_t *, unsigned long long *, TileCosts);
+        hybrid_fn hk = k_render_hybrid<F_ALL>;
+        if ((f & ~F_MESH) == 0) hk = k_render_hybrid<F_MESH>;
+        else if ((f & ~(F_MESH | F_SECONDARY)) == 0) hk = k_render_hybrid<F_MESH | F_SECONDARY>;
+        else if ((f & ~(F_MESH | F_TEXTURE | F_SECONDARY)) == 0) hk = k_render_hybrid<F_MESH | F_TEXTURE | F_SECONDARY>;
+        hipLaunchKernelGGL(hk, dim3(4 * local_tiles), dim3(kBlock), 0, ctx->stream, ctx->S, a, d_rgb_tiles, d_rgb8_tiles,
+                           ctx->d_counters, tc);
+    } else {
+        hipLaunchKernelGGL(kernel, dim3(blocks_per_tile * local_tiles), dim3(kBlock), 0, ctx->stream, ctx->S, a, d_rgb_tiles,
+                           d_rgb8_tiles, ctx->d_counters);
+    }
     RT_HIP(hipGetLastError());
     if (measure >= 0) {
         RT_HIP(hipEventRecord(ctx->tune.ev[measure][1], ctx->stream));

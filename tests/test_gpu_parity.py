@@ -412,17 +412,19 @@ def test_tall_tree_equals_brute_force_on_gpu(builder, monkeypatch):
 
 def test_render_kernel_choice_by_timing_keeps_the_pixels(gpu_ctx):
     """With new frame parameters the first launch runs the one-lane-per-pixel kernel, the second the kernel that
-    spreads a pixel's taps over a block's waves, a third the finer split if the plain one paid, and then the
-    fastest is kept: six frames, two or three kernels, the same bytes."""
+    spreads a pixel's taps over a block's waves; if that paid, the finer split and the per-tile choice (twice: it
+    learns in its first launch) follow, and then the fastest is kept: ten frames, up to four kernels, the same
+    bytes."""
     if os.environ.get("RT_SPLIT_MIN_TAPS"):
         pytest.skip("the environment fixes the kernel choice")
     ctx = gpu_ctx("teapot")
     frames, variants = [], []
-    for _ in range(6):
+    for _ in range(10):
         frames.append(ctx.render(333, 177, fov=77.0, mode=rt.MODE_GRID, grid_m=3))
         variants.append(ctx.counters().render_variant)
-    assert variants[:2] == [0, 1] and variants[2] in (0, 2) and variants[3] in (0, 1, 2)
-    assert variants[3] == variants[4] == variants[5]
+    assert variants[:2] == [0, 1]
+    assert variants[2:5] in ([2, 3, 3], [3, 3, variants[4]], [0, 0, 0]), variants
+    assert len(set(variants[5:])) == 1
     for rgb, rgb8 in frames[1:]:
         assert np.array_equal(rgb8, frames[0][1]) and np.array_equal(rgb, frames[0][0], equal_nan=True)
 
@@ -481,3 +483,35 @@ def test_half_a_million_triangles():
         assert np.isfinite(rgb).all() and rgb8.max() > 50
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("threshold", ["0", "3000", "20000", "4000000000"])
+def test_per_tile_kernel_choice_is_bit_identical(threshold, host_scene, monkeypatch):
+    """k_render_hybrid renders a tile either with one block (a lane per pixel) or with four (taps spread over the
+    waves), by the time the tile took in the frame before: whatever the threshold -- all tiles heavy from the
+    second frame on, a mix, none -- every frame equals k_render's."""
+    w, h = 200, 120
+    monkeypatch.setenv("RT_RENDER_VARIANT", "0")
+    ctx = rt.Context(0)
+    ctx.upload(host_scene("teapot"))
+    plain, plain8 = ctx.render(w, h, mode=rt.MODE_GRID, grid_m=3)
+    ctx.close()
+    monkeypatch.setenv("RT_RENDER_VARIANT", "3")
+    monkeypatch.setenv("RT_HYBRID_THRESHOLD", threshold)
+    ctx = rt.Context(0)
+    ctx.upload(host_scene("teapot"))
+    try:
+        for k in range(4):
+            rgb, rgb8 = ctx.render(w, h, mode=rt.MODE_GRID, grid_m=3)
+            assert ctx.counters().render_variant == 3
+            assert np.array_equal(rgb8, plain8) and np.array_equal(rgb, plain, equal_nan=True), (threshold, k)
+        # another frame size with the same context: the remembered times no longer fit, the pixels still do
+        a, a8 = ctx.render(96, 64, mode=rt.MODE_GRID, grid_m=2)
+        monkeypatch.setenv("RT_RENDER_VARIANT", "0")
+    finally:
+        ctx.close()
+    ctx = rt.Context(0)
+    ctx.upload(host_scene("teapot"))
+    b, b8 = ctx.render(96, 64, mode=rt.MODE_GRID, grid_m=2)
+    ctx.close()
+    assert np.array_equal(a8, b8) and np.array_equal(a, b, equal_nan=True)
