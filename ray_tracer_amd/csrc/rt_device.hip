@@ -1054,6 +1054,10 @@ extern "C" int rt_render_shard_device(rt_ctx *ctx, const rt_render_params *p, fl
             std::memcpy(t.key, key, sizeof key);
             t.valid = true;
             for (int v = 0; v < kRenderVariants; v++) t.recorded[v] = t.have[v] = false;
+            if (few_tiles) {  // k_render is known to lose here (a launch of few, very unequal blocks): not worth a frame
+                t.recorded[0] = t.have[0] = true;
+                t.ms[0] = INFINITY;
+            }
             t.choice = -1;
             new_key = true;
         }
@@ -1064,7 +1068,7 @@ extern "C" int rt_render_shard_device(rt_ctx *ctx, const rt_render_params *p, fl
         (void)hipGetLastError();  // hipErrorNotReady from the query is not an error of this call
         // k_render and the plain split kernel first.  Where splitting pays, the finer split is tried as well; where
         // it pays or nearly does (the longest blocks matter), the per-tile choice, which learns the tiles' times in
-        // its first launch, so that its second one is timed.  A tie goes to the simpler kernel.
+        // its first two launches, so that its third one is timed.  A tie goes to the simpler kernel.
         const bool both = t.have[0] && t.have[1];
         const bool pays = both && t.ms[1] < 0.98f * t.ms[0], near = both && t.ms[1] < 1.1f * t.ms[0];
         if (t.choice < 0 && both && (!pays || t.have[2]) && (!near || t.have[3])) {
@@ -1078,7 +1082,7 @@ extern "C" int rt_render_shard_device(rt_ctx *ctx, const rt_render_params *p, fl
         else if (!t.recorded[0]) variant = measure = 0;
         else if (!t.recorded[1]) variant = measure = 1;
         else if (pays && !t.recorded[2]) variant = measure = 2;
-        else if (near && ctx->hybrid_runs == 0) variant = 3;
+        else if (near && ctx->hybrid_runs < 2) variant = 3;  // all tiles split, then a first sorting: the third launch is the typical one
         else if (near && !t.recorded[3]) variant = measure = 3;
         else if (pays) variant = 1;  // waiting for the last timings
     }
