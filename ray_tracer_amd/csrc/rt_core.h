@@ -878,8 +878,6 @@ RT_HD void find_closest(const DevScene &S, v3 ro, v3 rd, int accel, int light, f
     const uint64_t finite = wave_ballot(adx < INFINITY) & wave_ballot(ady < INFINITY) & wave_ballot(adz < INFINITY) &
                             wave_ballot(aox < INFINITY) & wave_ballot(aoy < INFINITY) & wave_ballot(aoz < INFINITY);
     const bool meshes = (F & F_MESH) && S.n_meshes > 0;
-    u32x16 head_next = {};
-    if (meshes) head_next = load_u32x16(S.meshes);  // the first mesh head travels with the first planes
     for (int32_t i = 0; i < S.n_axis_planes; i += kAxisPlaneGroup) {
         u32x16 g = load_u32x16(S.axis_planes + i);
         pin_scalar(g);
@@ -922,8 +920,7 @@ RT_HD void find_closest(const DevScene &S, v3 ro, v3 rd, int accel, int light, f
     const int32_t n_meshes = S.n_meshes;
     for (int32_t i = 0; i < n_meshes; i++) {
         union { u32x16 raw; MeshHead h; } head;
-        head.raw = head_next;
-        if (i + 1 < n_meshes) head_next = load_u32x16(S.meshes + i + 1);
+        head.raw = load_u32x16(S.meshes + i);
         int32_t idx = head.h.object;
         if (idx < 0) continue;  // wave-uniform
         MeshHit mh;
