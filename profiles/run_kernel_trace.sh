@@ -8,5 +8,5 @@ cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$tag -o bench -- \
-    python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/prof_${tag}_bench.log 2>&1
+    python3 bench.py --steps 5 --warmup 3 --no-cpu-baseline > gpurun_out/prof_${tag}_bench.log 2>&1
 find gpurun_out/prof_$tag -name '*stats*' | head

@@ -10,7 +10,7 @@ mkdir -p gpurun_out/pmc_$tag
 run() {
     name=$1; shift
     timeout -s KILL 120 rocprofv3 --pmc "$@" --output-format csv -d gpurun_out/pmc_$tag/$name -o pmc -- \
-        python3 bench.py --steps 2 --warmup 2 --no-cpu-baseline > gpurun_out/pmc_$tag/$name.log 2>&1 || { echo "pass $name failed"; tail -5 gpurun_out/pmc_$tag/$name.log; return 1; }
+        python3 bench.py --steps 2 --warmup 3 --no-cpu-baseline > gpurun_out/pmc_$tag/$name.log 2>&1 || { echo "pass $name failed"; tail -5 gpurun_out/pmc_$tag/$name.log; return 1; }
     echo "pass $name ok"
 }
 run sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY || exit 1

@@ -552,6 +552,7 @@ struct rt_ctx {
         bool recorded[kRenderVariants] = {}, have[kRenderVariants] = {};
         float ms[kRenderVariants] = {};
         int choice = -1;
+        int launches = 0;  // with this key
     } tune;
     int split_phases = 1;  // RT_SPLIT_PHASES: which split kernel RT_SPLIT_MIN_TAPS selects
     // k_render_hybrid: the time every tile took in the last frame, two arrays used in turn (read one, write the other)
@@ -1059,6 +1060,7 @@ extern "C" int rt_render_shard_device(rt_ctx *ctx, const rt_render_params *p, fl
                 t.ms[0] = INFINITY;
             }
             t.choice = -1;
+            t.launches = 0;
             new_key = true;
         }
         for (int v = 0; v < kRenderVariants && t.choice < 0; v++)
@@ -1079,12 +1081,14 @@ extern "C" int rt_render_shard_device(rt_ctx *ctx, const rt_render_params *p, fl
         if (both)  // a tile is heavy when it takes 1.5 times the average tile's share of a launch
             threshold = (uint32_t)std::min(4.0e9, 1.5 * std::min(t.ms[0], t.ms[1]) * 5.0 * ctx->n_cus / local_tiles * 1.0e5);
         if (t.choice >= 0) variant = t.choice;
+        else if (t.launches == 0) {}  // the first launch runs cold (clocks, caches: 15 % slower): not one to time
         else if (!t.recorded[0]) variant = measure = 0;
         else if (!t.recorded[1]) variant = measure = 1;
         else if (pays && !t.recorded[2]) variant = measure = 2;
         else if (near && ctx->hybrid_runs < 2) variant = 3;  // all tiles split, then a first sorting: the third launch is the typical one
         else if (near && !t.recorded[3]) variant = measure = 3;
         else if (pays) variant = 1;  // waiting for the last timings
+        t.launches++;
     }
     if (ctx->forced_threshold >= 0) threshold = (uint32_t)std::min<long long>(ctx->forced_threshold, 0xffffffffll);
     if (p->count_work) variant = 0;  // (the counting instantiation exists for k_render and the split kernels; any gives the same counts)
