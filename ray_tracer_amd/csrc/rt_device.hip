@@ -1109,8 +1109,9 @@ extern "C" int rt_render_shard_device(rt_ctx *ctx, const rt_render_params *p, fl
     TileCosts tc = {nullptr, nullptr, threshold};
     if (variant == 3) {
         if (local_tiles > ctx->tile_cost_cap) {
+            ctx->tile_cost_cap = 0;  // (stays 0 if an allocation below fails)
+            RT_HIP(hipStreamSynchronize(ctx->stream));
             for (int k = 0; k < 2; k++) {
-                RT_HIP(hipStreamSynchronize(ctx->stream));
                 (void)hipFree(ctx->d_tile_cost[k]);
                 ctx->d_tile_cost[k] = nullptr;
                 RT_HIP(hipMalloc((void **)&ctx->d_tile_cost[k], (size_t)local_tiles * sizeof(uint32_t)));
