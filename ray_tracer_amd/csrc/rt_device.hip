@@ -1081,7 +1081,10 @@ extern "C" int rt_render_shard_device(rt_ctx *ctx, const rt_render_params *p, fl
         if (both)  // a tile is heavy when it takes 1.5 times the average tile's share of a launch
             threshold = (uint32_t)std::min(4.0e9, 1.5 * std::min(t.ms[0], t.ms[1]) * 5.0 * ctx->n_cus / local_tiles * 1.0e5);
         if (t.choice >= 0) variant = t.choice;
-        else if (t.launches == 0) {}  // the first launch runs cold (clocks, caches: 15 % slower): not one to time
+        // The first launch runs cold (clocks, caches: 15 % slower) and is not one to time.  Where the rule of thumb is
+        // on firm ground (many tiles) trying the other kernels costs more than a short sequence can win back: there
+        // the timing starts with the 16th frame.
+        else if (t.launches < (few_tiles ? 1 : 16)) {}
         else if (!t.recorded[0]) variant = measure = 0;
         else if (!t.recorded[1]) variant = measure = 1;
         else if (pays && !t.recorded[2]) variant = measure = 2;

@@ -411,20 +411,20 @@ def test_tall_tree_equals_brute_force_on_gpu(builder, monkeypatch):
 
 
 def test_render_kernel_choice_by_timing_keeps_the_pixels(gpu_ctx):
-    """With new frame parameters the first two launches run the one-lane-per-pixel kernel, the third the kernel that
+    """With new frame parameters the first seventeen launches run the one-lane-per-pixel kernel (the last one timed), the next the kernel that
     spreads a pixel's taps over a block's waves; if that paid, the finer split and the per-tile choice (twice: it
-    learns in its first launches) follow, and then the fastest is kept: eleven frames, up to four kernels, the
+    learns in its first launches) follow, and then the fastest is kept: 26 frames, up to four kernels, the
     same bytes."""
     if os.environ.get("RT_SPLIT_MIN_TAPS"):
         pytest.skip("the environment fixes the kernel choice")
     ctx = gpu_ctx("teapot")
     frames, variants = [], []
-    for _ in range(11):
+    for _ in range(26):
         frames.append(ctx.render(333, 177, fov=77.0, mode=rt.MODE_GRID, grid_m=3))
         variants.append(ctx.counters().render_variant)
-    assert variants[:3] == [0, 0, 1]  # (the first launch runs cold and is not timed)
-    assert variants[3:7] in ([2, 3, 3, 3], [3, 3, 3, variants[6]], [0, 0, 0, 0]), variants
-    assert len(set(variants[7:])) == 1
+    assert variants[:18] == [0] * 17 + [1]  # (no timing before the 16th frame of a sequence; then k_render, then the split)
+    assert variants[18:22] in ([2, 3, 3, 3], [3, 3, 3, variants[21]], [0, 0, 0, 0]), variants
+    assert len(set(variants[22:])) == 1
     for rgb, rgb8 in frames[1:]:
         assert np.array_equal(rgb8, frames[0][1]) and np.array_equal(rgb, frames[0][0], equal_nan=True)
 
