@@ -193,7 +193,7 @@ struct BvhNode {
 };
 
 // One mesh.  The first 64 bytes (MeshHead) are all that a ray needs to reject the mesh and to set up
-// the traversal; they are fetched as one scalar load, ahead of time.  The second block (to_local and
+// the traversal; they are fetched as one scalar load.  The second block (to_local and
 // the gate boxes) is read only by waves with a ray inside the world box.
 struct MeshHead {
     float world_lo[3], world_hi[3];  // padded world-space bounds of the (gate box of the) mesh: first, cheapest rejection
