@@ -307,6 +307,13 @@ __device__ __forceinline__ void render_tile(const DevScene &S, const RenderArgs 
         rgb8_tiles[p + 2] = inside ? quantise(t.z) : 0;
     }
 }
+// The kernel arguments arrive as wide scalar loads, and a register tuple that has to make room is saved and
+// restored whole (eight lane reads for one field, fifteen times in the tap loop of the split kernel).  After
+// this every field is a scalar register of its own.
+__device__ __forceinline__ void unbundle(RenderArgs &a) {
+    asm("" : "+s"(a.width), "+s"(a.height), "+s"(a.mode), "+s"(a.grid_m), "+s"(a.max_depth), "+s"(a.accel), "+s"(a.rank),
+             "+s"(a.world_size), "+s"(a.tiles_x), "+s"(a.tiles_total));
+}
 __device__ __forceinline__ void fill_grid_table(float *s_grid_off, const RenderArgs &a) {
     if (threadIdx.x < kMaxGrid) s_grid_off[threadIdx.x] = (int)threadIdx.x < a.grid_m ? grid_offset(threadIdx.x, a.grid_m, a.cam.s) : 0.0f;
     __syncthreads();
@@ -412,6 +419,7 @@ __device__ __forceinline__ void render_tile_part(const DevScene &S, const Render
 template <int F, bool COUNT, int PH>
 __global__ __launch_bounds__(kBlock, split_waves(F, COUNT)) void k_render_split(DevScene S, RenderArgs a, float *rgb_tiles,
                                                                                  uint8_t *rgb8_tiles, unsigned long long *counters) {
+    unbundle(a);
     RT_WAVE_STACK(stk, F);
     __shared__ float tap_lds[kRoundTaps * 3 * (64 / PH)];
     __shared__ float s_grid_off[kMaxGrid];
@@ -441,6 +449,7 @@ __global__ __launch_bounds__(kBlock, split_waves(F, false)) void k_render_hybrid
     const int worker = (int)(((uint32_t)local * 2654435761u) >> 13) & 3;
     if (!heavy && quad != worker) return;
     const unsigned long long t0 = wall_clock64();
+    unbundle(a);
     RT_WAVE_STACK(stk, F);
     __shared__ float tap_lds[kRoundTaps * 3 * 64];
     __shared__ float s_grid_off[kMaxGrid];
