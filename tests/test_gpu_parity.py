@@ -515,3 +515,27 @@ def test_per_tile_kernel_choice_is_bit_identical(threshold, host_scene, monkeypa
     b, b8 = ctx.render(96, 64, mode=rt.MODE_GRID, grid_m=2)
     ctx.close()
     assert np.array_equal(a8, b8) and np.array_equal(a, b, equal_nan=True)
+
+
+def test_command_line_driver_writes_the_same_frame(gpu_ctx, tmp_path):
+    """rt_main, the counterpart of the reference's `./main out.ppm` (main.cpp:1212-1288): its ASCII PPM holds the
+    frame the library renders through the Python binding, and a three-frame sequence differs from frame to frame."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(rt.__file__), "rt_main")
+    if not os.path.exists(exe):
+        pytest.fail("ray_tracer_amd/rt_main is missing: make -C ray_tracer_amd/csrc")
+    out = tmp_path / "teapot.ppm"
+    r = subprocess.run([exe, str(out), "--preset", "teapot", "--size", "96x64", "--mode", "grid2", "--assets", rt.ASSETS],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    tokens = out.read_text().split()
+    assert tokens[:4] == ["P3", "96", "64", "255"]
+    got = np.array(tokens[4:], np.int32).reshape(64, 96, 3)
+    _, rgb8 = gpu_ctx("teapot").render(96, 64, mode=rt.MODE_GRID, grid_m=2)
+    assert np.array_equal(got, rgb8)
+    seq = tmp_path / "turn.ppm"
+    r = subprocess.run([exe, str(seq), "--preset", "teapot", "--size", "64x48", "--frames", "3", "--p6", "--assets", rt.ASSETS],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    frames = [(tmp_path / f"turn_{k:04d}.ppm").read_bytes() for k in range(3)]
+    assert all(f.startswith(b"P6") for f in frames) and len(set(frames)) == 3
