@@ -157,7 +157,9 @@ def main():
         value = rays_total / elapsed / 1e6
         traffic = None
         pmc_path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(pmc_path):
+        kernel_names = ("k_render", "k_render_split<1>", "k_render_split<2>", "k_render_hybrid")
+        # the counter passes were made on the single-GPU launch of k_render: no figure for a rank's share
+        if world == 1 and c.render_variant == 0 and os.path.exists(pmc_path):
             try:
                 traffic = json.load(open(pmc_path)).get(args.workload)
             except Exception:
@@ -174,10 +176,10 @@ def main():
                        "parallelism": f"tiles{world}", "rays_per_frame": rays_total / args.steps,
                        "bvh_height": c.bvh_max_depth, "lbvh_build_ms": c.last_build_ms,
                        "tree_build": "radix" if os.environ.get("RT_BUILD") == "radix" else "binned surface-area splits",
-                       "render_kernel": ("k_render", "k_render_split<1>", "k_render_split<2>", "k_render_hybrid")[c.render_variant]},
+                       "render_kernel": kernel_names[c.render_variant]},
             "roofline": {"bound": "valu", "achieved": achieved_tflops, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved_tflops / PEAK_FP32_TFLOPS, "traffic": traffic,
-                         "kernel": "k_render", "kernel_ms": kernel_ms,
+                         "kernel": kernel_names[c.render_variant], "kernel_ms": kernel_ms,
                          "counts_per_launch": {"tri_tests": cw.tri_tests, "box_tests": cw.box_tests,
                                                "gate_tests": cw.gate_tests, "quadric_tests": cw.quadric_tests,
                                                "plane_tests": cw.plane_tests, "shade_evals": cw.shade_evals,
