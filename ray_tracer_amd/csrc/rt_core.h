@@ -247,11 +247,24 @@ struct DevTexture {
     const void *pad2[3];
 };
 
+// Per sphere: its index in `objects` (-1: not in the object list) and a ball in world space that contains
+// it with room to spare (sphere_culls() in rt_prepare.h says how much): rays that pass the ball, leave it
+// behind or cannot reach it within the best distance so far skip the sphere's exact test.
+struct SphereCull {
+    float c[3];
+    float r2;        // squared radius
+    float r;
+    float keep;      // factors <= 1 on the squared distance of the ray's origin from the centre: the room the
+    float keep_far;  // rounding of the exact test needs, which grows with that distance (0: never skip)
+    int32_t object;
+};
+
 struct DevScene {
     int32_t n_objects, n_lights;
     int32_t n_planes, n_spheres, n_cones, n_meshes;
     const rt_object *objects;
-    const int32_t *plane_obj, *sphere_obj, *cone_obj;  // index of each plane / ... in `objects` (meshes: MeshHead::object)
+    const int32_t *plane_obj, *cone_obj;  // index of each plane / cone in `objects` (meshes: MeshHead::object)
+    const SphereCull *sphere_cull;
     int32_t n_axis_planes, n_gen_planes;  // padded counts
     const AxisPlaneRec *axis_planes;
     const PlaneRec *gen_planes;
@@ -376,6 +389,23 @@ struct QuadricHit {
     float distance;
     v3 o, d, i; // local ray and local hit point
 };
+
+// True when the exact test below cannot produce a hit that find_closest would keep: the ray's line passes
+// the ball, or the ball lies behind the origin, or its nearest point is farther than the best distance so
+// far (a sphere reports the Euclidean distance of its hit point, main.cpp:183).  The exact test is float
+// arithmetic on local coordinates: its discriminant is uncertain by 6e-7 |o|^2 (o: the local origin) in
+// units of the squared local distance between line and centre, so far-away rays "hit" a shell around the
+// sphere that grows with |o|.  `keep` and `keep_far` shrink |oc|^2 by that shell (with margins, see
+// sphere_culls() in rt_prepare.h), so that every ray the exact test could accept passes this test.
+// NaN operands make every comparison false.
+RT_HD bool misses_ball(const SphereCull &k, v3 ro, v3 rd, float best_distance) {
+    v3 oc = V3(k.c[0], k.c[1], k.c[2]) - ro;
+    float occ = dot(oc, oc);
+    float b = dot(oc, rd), dd = dot(rd, rd);
+    float out = occ * k.keep - k.r2;  // > 0: the origin is outside the ball and its shell
+    float reach = best_distance + k.r;
+    return (dd * out > b * b) | ((out > 0) & (b < 0)) | (occ * k.keep_far > reach * reach);
+}
 
 // Sphere::intersect, main.cpp:122-160 + 183 (geometry, acceptance inputs).  pow(x, 2) on floats is
 // double arithmetic in the reference.
@@ -895,9 +925,11 @@ RT_HD void find_closest(const DevScene &S, v3 ro, v3 rd, int accel, int light, f
     if (F & F_QUADRIC)
     for (int32_t i = 0; i < S.n_spheres; i++) {
         QuadricHit q;
-        if (COUNT) wk.quadric++;
-        int32_t idx = S.sphere_obj[i];
+        const SphereCull &k = S.sphere_cull[i];
+        int32_t idx = k.object;
         if (idx < 0) continue;
+        if (misses_ball(k, ro, rd, best.distance)) continue;
+        if (COUNT) wk.quadric++;
         if (sphere_geom(S.spheres[i], ro, rd, q) && q.from_outside && closer(q.distance, idx, best)) {
             best.distance = q.distance; best.object = idx; best.t = q.t; best.k = 0;
         }

@@ -726,9 +726,12 @@ extern "C" int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *sc) {
     if ((rc = dev_alloc(ctx, &d_tex, tex.size(), tex.data()))) return rc;
     std::vector<int32_t> plane_obj, sphere_obj, cone_obj, mesh_obj;
     kind_to_object(sc, plane_obj, sphere_obj, cone_obj, mesh_obj);
-    int32_t *d_plane_obj, *d_sphere_obj, *d_cone_obj;
+    int32_t *d_plane_obj, *d_cone_obj;
+    SphereCull *d_sphere_cull;
+    std::vector<SphereCull> sphere_cull;
+    sphere_culls(sc, sphere_obj, sphere_cull);
     if ((rc = dev_alloc(ctx, &d_plane_obj, plane_obj.size(), plane_obj.data()))) return rc;
-    if ((rc = dev_alloc(ctx, &d_sphere_obj, sphere_obj.size(), sphere_obj.data()))) return rc;
+    if ((rc = dev_alloc(ctx, &d_sphere_cull, sphere_cull.size(), sphere_cull.data()))) return rc;
     if ((rc = dev_alloc(ctx, &d_cone_obj, cone_obj.size(), cone_obj.data()))) return rc;
     std::vector<AxisPlaneRec> axis_planes;
     std::vector<PlaneRec> gen_planes;
@@ -784,7 +787,7 @@ extern "C" int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *sc) {
     S.n_planes = sc->n_planes; S.n_spheres = sc->n_spheres; S.n_cones = sc->n_cones; S.n_meshes = sc->n_meshes;
     S.n_axis_planes = (int32_t)axis_planes.size(); S.n_gen_planes = (int32_t)gen_planes.size();
     S.axis_planes = d_axis_planes; S.gen_planes = d_gen_planes;
-    S.plane_obj = d_plane_obj; S.sphere_obj = d_sphere_obj; S.cone_obj = d_cone_obj;
+    S.plane_obj = d_plane_obj; S.sphere_cull = d_sphere_cull; S.cone_obj = d_cone_obj;
     S.objects = d_objects; S.spheres = d_spheres; S.planes = d_planes; S.cones = d_cones; S.meshes = ctx->d_meshes;
     S.tri_test = ctx->d_tri_test; S.tri_key = ctx->d_tri_key; S.tri_orig = ctx->d_tri_orig;
     S.tri_nrm = d_nrm; S.tri_uv = d_uv; S.tri_material = d_tmat; S.tri_frag = ctx->d_tri_frag; S.tri_sub = ctx->d_tri_sub;
@@ -842,7 +845,9 @@ extern "C" int rt_scene_update(rt_ctx *ctx, const rt_scene_desc *sc) {
     std::vector<int32_t> plane_obj, sphere_obj, cone_obj, mesh_obj;
     kind_to_object(sc, plane_obj, sphere_obj, cone_obj, mesh_obj);
     if ((rc = dev_update(ctx, S.plane_obj, plane_obj.data(), plane_obj.size()))) return rc;
-    if ((rc = dev_update(ctx, S.sphere_obj, sphere_obj.data(), sphere_obj.size()))) return rc;
+    std::vector<SphereCull> sphere_cull;
+    sphere_culls(sc, sphere_obj, sphere_cull);
+    if ((rc = dev_update(ctx, S.sphere_cull, sphere_cull.data(), sphere_cull.size()))) return rc;
     if ((rc = dev_update(ctx, S.cone_obj, cone_obj.data(), cone_obj.size()))) return rc;
     std::vector<AxisPlaneRec> axis_planes;
     std::vector<PlaneRec> gen_planes;
@@ -1114,6 +1119,7 @@ extern "C" int rt_render_shard_device(rt_ctx *ctx, const rt_render_params *p, fl
     else if ((f & ~F_MESH) == 0) kernel = RT_PICK(F_MESH, false);
     else if ((f & ~(F_MESH | F_SECONDARY)) == 0) kernel = RT_PICK(F_MESH | F_SECONDARY, false);
     else if ((f & ~(F_QUADRIC | F_SECONDARY)) == 0) kernel = RT_PICK(F_QUADRIC | F_SECONDARY, false);
+    else if ((f & ~(F_QUADRIC | F_TEXTURE | F_SECONDARY)) == 0) kernel = RT_PICK(F_QUADRIC | F_TEXTURE | F_SECONDARY, false);
     else if ((f & ~(F_MESH | F_TEXTURE | F_SECONDARY)) == 0) kernel = RT_PICK(F_MESH | F_TEXTURE | F_SECONDARY, false);
     else kernel = RT_PICK(F_ALL, false);
 #undef RT_PICK

@@ -176,6 +176,88 @@ inline void kind_to_object(const rt_scene_desc *sc, std::vector<int32_t> &plane_
     }
 }
 
+// Largest stretch (spectral norm) of the linear part of a 3x4 map stored by columns: square root of the
+// largest eigenvalue of A^T A by the trigonometric formula for symmetric 3x3 matrices, kept between the
+// two elementary bounds (longest column <= norm <= Frobenius norm) whatever rounding does to the formula.
+inline double largest_stretch(const double A[3][3]) {
+    double S[3][3], frob = 0, col = 0;
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) {
+            S[i][j] = A[0][i] * A[0][j] + A[1][i] * A[1][j] + A[2][i] * A[2][j];
+            if (i == j) { frob += S[i][i]; col = std::max(col, S[i][i]); }
+        }
+    if (!std::isfinite(frob)) return NAN;
+    double q = frob / 3, p1 = S[0][1] * S[0][1] + S[0][2] * S[0][2] + S[1][2] * S[1][2];
+    double p2 = (S[0][0] - q) * (S[0][0] - q) + (S[1][1] - q) * (S[1][1] - q) + (S[2][2] - q) * (S[2][2] - q) + 2 * p1;
+    double top = q;
+    if (p2 > 0) {
+        double p = std::sqrt(p2 / 6), B[3][3];
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) B[i][j] = (S[i][j] - (i == j ? q : 0)) / p;
+        double det = B[0][0] * (B[1][1] * B[2][2] - B[1][2] * B[2][1]) - B[0][1] * (B[1][0] * B[2][2] - B[1][2] * B[2][0]) +
+                     B[0][2] * (B[1][0] * B[2][1] - B[1][1] * B[2][0]);
+        double r = std::min(1.0, std::max(-1.0, det / 2));
+        top = q + 2 * p * std::cos(std::acos(r) / 3);
+    }
+    if (!(top >= col)) top = col;
+    if (!(top <= frob)) top = frob;
+    return std::sqrt(top);
+}
+
+// The ball of every sphere (SphereCull).  A ray is tested in the sphere's own space through `to_local`
+// and its hit point comes back through `to_world` (main.cpp:124-125, 163), two float matrices that are
+// inverses of each other only up to rounding: the ball is taken around the image of the unit sphere
+// under `to_world`, wide enough for the one under the inverse of `to_local` as well, then widened by 1e-3
+// of its radius and by 1e-5 of its distance from the origin (the float transformations round coordinates
+// of that size to ~1e-7 of it).
+// The shell: Sphere::intersect forms b = 2 d.o in float (error <= 1.8e-7 |d||o|), 4ac as a float product of
+// floats (2.4e-7 relative) and a, c rounded to float, so delta / (4 d.d) = 1 - (distance line-centre)^2 is
+// uncertain by 6e-7 |o|^2, and the roots lie inside the chord of a unit sphere inflated by that much again.
+// With |o| <= |oc| * stretch(to_local) and world distances <= stretch(to_world) * local distances, every
+// accepted hit lies in the ball of squared radius r^2 + s |oc|^2, s = 8e-6 kappa^2 (kappa = the product of
+// the two stretches, the condition number; a factor 2 on top of 2 x 2e-6).  keep = 1 - s - 1e-5 and
+// keep_far = (1 - sqrt(s))^2 - 1e-5 apply it to the squared distance and to the distance; at kappa ~ 350
+// they reach 0 and the sphere is always tested.  Non-finite matrices: NaN radius, never skipped.
+inline void sphere_culls(const rt_scene_desc *sc, const std::vector<int32_t> &sphere_obj, std::vector<SphereCull> &out) {
+    out.assign(sc->n_spheres, SphereCull{});
+    for (int i = 0; i < sc->n_spheres; i++) {
+        const rt_sphere &sp = sc->spheres[i];
+        double W[3][3], L[3][3], c[3], tl[3];
+        for (int r = 0; r < 3; r++) {
+            for (int k = 0; k < 3; k++) { W[r][k] = sp.to_world[3 * k + r]; L[r][k] = sp.to_local[3 * k + r]; }
+            c[r] = sp.to_world[9 + r]; tl[r] = sp.to_local[9 + r];
+        }
+        double radius = largest_stretch(W);
+        // the same from to_local: x = L^-1 (u - t) for |u| <= 1
+        double det = L[0][0] * (L[1][1] * L[2][2] - L[1][2] * L[2][1]) - L[0][1] * (L[1][0] * L[2][2] - L[1][2] * L[2][0]) +
+                     L[0][2] * (L[1][0] * L[2][1] - L[1][1] * L[2][0]);
+        double I[3][3];
+        I[0][0] = (L[1][1] * L[2][2] - L[1][2] * L[2][1]) / det; I[0][1] = (L[0][2] * L[2][1] - L[0][1] * L[2][2]) / det;
+        I[0][2] = (L[0][1] * L[1][2] - L[0][2] * L[1][1]) / det; I[1][0] = (L[1][2] * L[2][0] - L[1][0] * L[2][2]) / det;
+        I[1][1] = (L[0][0] * L[2][2] - L[0][2] * L[2][0]) / det; I[1][2] = (L[0][2] * L[1][0] - L[0][0] * L[1][2]) / det;
+        I[2][0] = (L[1][0] * L[2][1] - L[1][1] * L[2][0]) / det; I[2][1] = (L[0][1] * L[2][0] - L[0][0] * L[2][1]) / det;
+        I[2][2] = (L[0][0] * L[1][1] - L[0][1] * L[1][0]) / det;
+        double shift = 0;
+        for (int r = 0; r < 3; r++) {
+            double c2 = -(I[r][0] * tl[0] + I[r][1] * tl[1] + I[r][2] * tl[2]);
+            shift += (c2 - c[r]) * (c2 - c[r]);
+        }
+        double other = largest_stretch(I) + std::sqrt(shift);
+        if (other > radius || other != other) radius = other;  // (NaN from a singular to_local stays NaN)
+        double far = std::sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
+        radius = radius * 1.001 + 1e-5 * (far + radius);
+        SphereCull &k = out[i];
+        for (int r = 0; r < 3; r++) k.c[r] = (float)c[r];
+        k.r = (float)(radius * 1.000001);  // (rounding to float must not shrink it)
+        k.r2 = (float)(radius * radius * 1.000001);
+        double kappa = largest_stretch(W) * largest_stretch(L), shell = 8e-6 * kappa * kappa;
+        if (!(shell < 1)) shell = 1;  // (also for NaN)
+        k.keep = (float)std::max(0.0, 1 - shell - 1e-5);
+        k.keep_far = (float)std::max(0.0, (1 - std::sqrt(shell)) * (1 - std::sqrt(shell)) - 1e-5);
+        k.object = sphere_obj[i];
+    }
+}
+
 // Fills the device-side mesh records (everything but device pointers), the per-mesh build data and
 // the gate triangles (36 f4 per mesh).  Returns the total number of LBVH nodes.
 // refs == true: also cuts the meshes into references (ref_pos, ref_tri); false: the reference ranges in

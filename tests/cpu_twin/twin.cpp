@@ -43,6 +43,7 @@ struct Twin {
     std::vector<int32_t> tri_orig, tri_material, tri_frag, tri_sub;
     std::vector<int32_t> plane_obj, sphere_obj, cone_obj, mesh_obj;
     std::vector<LightCull> light_cull;
+    std::vector<SphereCull> sphere_cull;
     std::vector<AxisPlaneRec> axis_planes;
     std::vector<PlaneRec> gen_planes;
     std::vector<float> ref_pos, leaf_box;  // pieces the triangles are cut into; boxes of the sorted pieces
@@ -186,7 +187,8 @@ void *twin_create(const rt_scene_desc *sc, char *errbuf, int errcap) {
     make_plane_recs(sc, t->plane_obj, t->axis_planes, t->gen_planes);
     S.n_axis_planes = (int32_t)t->axis_planes.size(); S.n_gen_planes = (int32_t)t->gen_planes.size();
     S.axis_planes = t->axis_planes.data(); S.gen_planes = t->gen_planes.data();
-    S.plane_obj = t->plane_obj.data(); S.sphere_obj = t->sphere_obj.data(); S.cone_obj = t->cone_obj.data();
+    sphere_culls(sc, t->sphere_obj, t->sphere_cull);
+    S.plane_obj = t->plane_obj.data(); S.sphere_cull = t->sphere_cull.data(); S.cone_obj = t->cone_obj.data();
     S.objects = t->objects.data(); S.spheres = t->spheres.data(); S.planes = t->planes.data(); S.cones = t->cones.data();
     S.meshes = t->meshes.data(); S.tri_test = t->tri_test.data(); S.tri_key = t->tri_key.data(); S.tri_orig = t->tri_orig.data();
     S.tri_nrm = t->tri_nrm.data(); S.tri_uv = t->tri_uv.data(); S.tri_material = t->tri_material.data();

@@ -171,3 +171,43 @@ def rays(sp, seed, w=72, h=54, n_random=1200):
     rd = rng.normal(size=(n_random, 3))
     return (np.concatenate([o, np.zeros_like(t), ro]).astype(np.float32),
             np.concatenate([d, t, rd]).astype(np.float32))
+
+
+def ellipsoids(seed):
+    """-> (ScenePair, origins, directions): spheres under hard transformations (axis ratios up to 60:1, turned,
+    tiny and far away, huge and near, far from the world's origin) in front of a back wall, and rays that graze
+    them: through points at (1 + e) times the tangent points seen from each ray's origin, e from -1e-2 to 1e-2,
+    plus rays from inside the spheres and rays that leave them behind."""
+    rng = np.random.default_rng(3000 + seed)
+    sp = ScenePair()
+    sp.plane((0, 0, 4000), (0, 0, -1), _material(rng, "diffuse"))
+    mats = []
+    for k in range(7):
+        centre = [(0, 0, 12), (300, -80, 900), (-2, 1, 6), (1500, 1500, 3000), (0.5, -0.5, 3), (-40, 10, 60), (3, 2, 20)][k]
+        scl = [(1, 1, 1), (0.05, 0.05, 0.05), (3, 0.05, 1), (60, 1, 20), (0.02, 0.5, 0.1), (8, 8, 8), (1, 2.5, 0.7)][k]
+        M = rt.translate(centre)
+        M = rt.rotate(rng.uniform(0, 6.28), rng.normal(size=3), M)
+        M = rt.scale(scl, M)
+        sp.sphere(M, _material(rng, ["diffuse", "shiny", "mirror", "glass"][k % 4]))
+        mats.append(np.asarray(M, np.float64).reshape(4, 4).T)  # (stored by columns)
+    sp.light((0, 50, -10), (1, 1, 1))
+    os_, ds_ = [], []
+    for M in mats:
+        Mi = np.linalg.inv(M)
+        for _ in range(60):
+            O = rng.uniform(-30, 30, 3) * np.array([1, 1, 0.3]) + np.array([0, 0, -5])
+            ol = Mi[:3, :3] @ O + Mi[:3, 3]
+            n2 = ol @ ol
+            if n2 <= 1.0:
+                continue
+            w = np.cross(ol, rng.normal(size=3)); w /= np.linalg.norm(w)
+            u = ol / n2 + np.sqrt(1 - 1 / n2) * w  # |u| = 1 and u . ol = 1: a tangent point seen from O
+            for e in (-1e-2, -1e-3, -1e-4, -1e-5, -1e-6, 0.0, 1e-6, 1e-5, 1e-4, 1e-3, 1e-2):
+                P = M[:3, :3] @ (u * (1 + e)) + M[:3, 3]
+                os_.append(O); ds_.append(P - O)
+                os_.append(O); ds_.append((P - O) / np.linalg.norm(P - O))
+            os_.append(O); ds_.append(O - (M[:3, 3]))  # away from it
+        for _ in range(20):  # from inside
+            u = rng.normal(size=3); u *= rng.uniform(0, 0.99) / np.linalg.norm(u)
+            os_.append(M[:3, :3] @ u + M[:3, 3]); ds_.append(rng.normal(size=3))
+    return sp, np.asarray(os_, np.float32), np.asarray(ds_, np.float32)

@@ -454,6 +454,30 @@ def test_random_scene_equals_oracle_on_gpu(seed):
     parity.check_rgb8(ref_rgb8, rgb8, what)
 
 
+@pytest.mark.parametrize("seed", range(3))
+def test_sphere_ball_test_drops_no_hit_on_gpu(seed):
+    """Spheres under hard transformations (axis ratios up to 60:1, tiny and far, far from the world's origin)
+    and rays that graze them, leave them behind or start inside: the ball test in front of the exact sphere
+    test never drops a hit the oracle, which has no such test, finds; shadow rays from a wall 4000 units
+    away cover the shell of rounding "hits" that far-away rays see around a sphere."""
+    import random_scenes
+    sp, o, d = random_scenes.ellipsoids(seed)
+    ref = sp.orc.find_closest_hit(o, d)
+    ref_rad, _ = sp.orc.trace_rays(o, d, 6)
+    ref_rgb, ref_rgb8, _ = sp.orc.render(96, 72, mode=rt.MODE_REF_AA9, max_depth=6)
+    ctx = rt.Context(0)
+    try:
+        ctx.upload(sp.host)
+        hits, rad = ctx.trace_rays(o, d, 6, rt.ACCEL_LBVH)
+        rgb, rgb8 = ctx.render(96, 72, mode=rt.MODE_REF_AA9, max_depth=6)
+    finally:
+        ctx.close()
+    parity.check_hits(ref, hits, "ellipsoids")
+    parity.check_radiance(ref_rad, rad, "ellipsoids")
+    parity.check_radiance(ref_rgb, rgb, "ellipsoids frame")
+    parity.check_rgb8(ref_rgb8, rgb8, "ellipsoids frame")
+
+
 def test_half_a_million_triangles():
     """A closed bumpy surface of 500 000 triangles behind a Box gate: upload, cut, sort, build (a tree of about
     twenty levels, one launch each) and fit stay within seconds, and the tree gives the records of the linear scan."""

@@ -145,6 +145,21 @@ def test_random_scene_equals_oracle(seed):
     assert (ref["hit"] == 1).mean() > 0.5
 
 
+@pytest.mark.parametrize("seed", range(3))
+def test_sphere_ball_test_drops_no_hit(seed):
+    """Spheres under hard transformations, rays that graze them: the ball test in front of the exact sphere
+    test (`misses_ball`) never drops a hit the oracle, which has no such test, finds."""
+    sp, o, d = random_scenes.ellipsoids(seed)
+    ref = sp.orc.find_closest_hit(o, d)
+    ref_rad, _ = sp.orc.trace_rays(o, d, 6)
+    tw = T.Twin(sp.host)
+    hits, rad = tw.trace_rays(o, d, 6, rt.ACCEL_LBVH)
+    parity.check_hits(ref, hits, "ellipsoids")
+    parity.check_radiance(ref_rad, rad, "ellipsoids")
+    on_sphere = (ref["hit"] == 1) & (ref["object"] >= 1)
+    assert 0.2 < on_sphere.mean() < 0.9  # grazing rays fall on both sides
+
+
 def C_byref(x):
     import ctypes
     return ctypes.byref(x)
