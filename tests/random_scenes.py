@@ -174,7 +174,7 @@ def rays(sp, seed, w=72, h=54, n_random=1200):
 
 
 def ellipsoids(seed):
-    """-> (ScenePair, origins, directions): spheres under hard transformations (axis ratios up to 60:1, turned,
+    """-> (ScenePair, origins, directions): spheres and cones under hard transformations (axis ratios up to 60:1, turned,
     tiny and far away, huge and near, far from the world's origin) in front of a back wall, and rays that graze
     them: through points at (1 + e) times the tangent points seen from each ray's origin, e from -1e-2 to 1e-2,
     plus rays from inside the spheres and rays that leave them behind."""
@@ -190,8 +190,37 @@ def ellipsoids(seed):
         M = rt.scale(scl, M)
         sp.sphere(M, _material(rng, ["diffuse", "shiny", "mirror", "glass"][k % 4]))
         mats.append(np.asarray(M, np.float64).reshape(4, 4).T)  # (stored by columns)
+    cones = []
+    for k in range(4):
+        centre = [(5, -2, 15), (-300, 40, 800), (-1, 3, 5), (20, 20, 70)][k]
+        scl = [(1, 3, 1), (2, 30, 2), (0.3, 0.1, 2), (6, 6, 6)][k]
+        M = rt.translate(centre)
+        M = rt.rotate(rng.uniform(0, 6.28), rng.normal(size=3), M)
+        M = rt.scale(scl, M)
+        sp.cone(M, _material(rng, ["shiny", "diffuse", "mirror", "glass"][k]))
+        cones.append(np.asarray(M, np.float64).reshape(4, 4).T)
     sp.light((0, 50, -10), (1, 1, 1))
     os_, ds_ = [], []
+    for M in cones:  # rays that graze the cone's surface at heights -3 .. 3 (apex 0, cap 1), shallow and steep
+        Mi = np.linalg.inv(M)
+        for _ in range(60):
+            y = rng.choice([-3, -1, -0.3, -0.01, 0.01, 0.3, 0.7, 0.99, 1.01, 1.5, 3])
+            phi = rng.uniform(0, 6.28)
+            surf = np.array([abs(y) * np.cos(phi), y, abs(y) * np.sin(phi)])
+            nrm = np.array([np.cos(phi), -np.sign(y), np.sin(phi)]) / np.sqrt(2)  # outward normal of the nappe
+            tang = np.cross(nrm, rng.normal(size=3)); tang /= np.linalg.norm(tang)
+            dist = rng.choice([3.0, 30.0, 300.0, 3000.0, 30000.0])
+            for e in (-1e-2, -1e-3, -1e-4, -1e-5, 0.0, 1e-5, 1e-4, 1e-3, 1e-2):
+                Pl = surf + nrm * e * max(abs(y), 0.1)
+                Ol = Pl - tang * dist
+                O = M[:3, :3] @ Ol + M[:3, 3]; P = M[:3, :3] @ Pl + M[:3, 3]
+                os_.append(O); ds_.append(P - O)
+                os_.append(O); ds_.append((P - O) / np.linalg.norm(P - O))
+        for _ in range(40):  # and rays at the ball around apex..cap from outside
+            O = rng.uniform(-30, 30, 3) + np.array([0, 0, -5])
+            Pl = np.array([0, 0.5, 0]) + rng.normal(size=3) * 0.9
+            P = M[:3, :3] @ Pl + M[:3, 3]
+            os_.append(O); ds_.append(P - O)
     for M in mats:
         Mi = np.linalg.inv(M)
         for _ in range(60):

@@ -147,8 +147,8 @@ def test_random_scene_equals_oracle(seed):
 
 @pytest.mark.parametrize("seed", range(3))
 def test_sphere_ball_test_drops_no_hit(seed):
-    """Spheres under hard transformations, rays that graze them: the ball test in front of the exact sphere
-    test (`misses_ball`) never drops a hit the oracle, which has no such test, finds."""
+    """Spheres and cones under hard transformations, rays that graze them: the ball tests in front of the exact
+    tests (`misses_ball`, `misses_cone`) never drop a hit the oracle, which has no such test, finds."""
     sp, o, d = random_scenes.ellipsoids(seed)
     ref = sp.orc.find_closest_hit(o, d)
     ref_rad, _ = sp.orc.trace_rays(o, d, 6)
@@ -156,8 +156,9 @@ def test_sphere_ball_test_drops_no_hit(seed):
     hits, rad = tw.trace_rays(o, d, 6, rt.ACCEL_LBVH)
     parity.check_hits(ref, hits, "ellipsoids")
     parity.check_radiance(ref_rad, rad, "ellipsoids")
-    on_sphere = (ref["hit"] == 1) & (ref["object"] >= 1)
-    assert 0.2 < on_sphere.mean() < 0.9  # grazing rays fall on both sides
+    on_sphere = (ref["hit"] == 1) & (ref["object"] >= 1) & (ref["object"] <= 7)
+    on_cone = (ref["hit"] == 1) & (ref["object"] >= 8)
+    assert 0.03 < on_sphere.mean() < 0.9 and 0.03 < on_cone.mean() < 0.9  # grazing rays fall on both sides
 
 
 def C_byref(x):
