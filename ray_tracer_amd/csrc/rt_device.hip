@@ -466,24 +466,45 @@ __global__ __launch_bounds__(kBlock, split_waves(F, false)) void k_render_hybrid
     }
 }
 
-// shards[r][local_tile][16][16][3] -> frame[y][x][3]; first_rank/n_ranks select which shards exist
+// shards[r][local_tile][16][16][3] -> frame[y][x][3]; first_rank/n_ranks select which shards exist.
+// A row of a tile is 48 * sizeof(T) contiguous bytes on both sides: one thread moves 16 of them, so a wave
+// reads 1 KiB of consecutive shard bytes and writes whole 48- or 192-byte runs of the frame.  `vec`: both
+// buffers are 16-byte aligned and so is every frame row; tiles that stick out of the frame, and any
+// other buffers, go byte by byte.
+template <typename T>
+constexpr int untile_chunks_per_tile() { return RT_TILE_W * 3 * (int)sizeof(T) / 16 * RT_TILE_H; }
 template <typename T>
 __global__ void k_untile(const T *shards, T *frame, int width, int height, int tiles_x, int tiles_total,
-                         int tiles_per_rank, int world_size, int first_rank, int n_ranks) {
+                         int tiles_per_rank, int world_size, int first_rank, int n_ranks, int vec) {
+    constexpr int kPixelBytes = 3 * (int)sizeof(T), kChunks = RT_TILE_W * kPixelBytes / 16, kTileChunks = untile_chunks_per_tile<T>();
+    static_assert(RT_TILE_W * kPixelBytes % 16 == 0, "a tile row is a whole number of 16-byte pieces");
     size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    size_t per_tile = RT_TILE_W * RT_TILE_H;
-    size_t total = (size_t)n_ranks * tiles_per_rank * per_tile;
+    size_t total = (size_t)n_ranks * tiles_per_rank * kTileChunks;
     if (idx >= total) return;
-    int within = (int)(idx % per_tile);
-    size_t tl = idx / per_tile;
+    int within = (int)(idx % kTileChunks);
+    size_t tl = idx / kTileChunks;
     int local = (int)(tl % tiles_per_rank), r = (int)(tl / tiles_per_rank) + first_rank;
     int tile = local * world_size + r;
     if (tile >= tiles_total) return;
-    int x = (tile % tiles_x) * RT_TILE_W + within % RT_TILE_W, y = (tile / tiles_x) * RT_TILE_H + within / RT_TILE_W;
-    if (x >= width || y >= height) return;
-    const T *src = shards + idx * 3;
-    T *dst = frame + ((size_t)y * width + x) * 3;
-    dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2];
+    int row = within / kChunks, part = within % kChunks;
+    int x0 = (tile % tiles_x) * RT_TILE_W, y = (tile / tiles_x) * RT_TILE_H + row;
+    if (y >= height) return;
+    const unsigned char *src = reinterpret_cast<const unsigned char *>(shards) + idx * 16;
+    unsigned char *dst = reinterpret_cast<unsigned char *>(frame) + ((size_t)y * width + x0) * kPixelBytes + part * 16;
+    if (vec && x0 + RT_TILE_W <= width) {
+        *reinterpret_cast<uint4 *>(dst) = *reinterpret_cast<const uint4 *>(src);
+        return;
+    }
+    for (int j = 0; j < 16; j++)
+        if (x0 + (part * 16 + j) / kPixelBytes < width) dst[j] = src[j];
+}
+// grid size and `vec` for a launch over `tiles` tiles
+template <typename T>
+static void untile_launch_shape(size_t tiles, const T *shards, const T *frame, int width, dim3 &grid, int &vec) {
+    size_t chunks = tiles * untile_chunks_per_tile<T>();
+    grid = dim3((unsigned)((chunks + 255) / 256));
+    vec = (reinterpret_cast<uintptr_t>(shards) % 16 == 0 && reinterpret_cast<uintptr_t>(frame) % 16 == 0 &&
+           ((size_t)width * 3 * sizeof(T)) % 16 == 0) ? 1 : 0;
 }
 
 __global__ __launch_bounds__(kBlock) void k_trace_rays(DevScene S, long long n, const float *o, const float *d,
@@ -1176,14 +1197,19 @@ static int untile_on(rt_ctx *ctx, hipStream_t stream, const rt_render_params *p,
     int per_rank, total;
     rt_shard_tiles(p, &per_rank, &total);
     int tiles_x = (p->width + RT_TILE_W - 1) / RT_TILE_W;
-    size_t elems = (size_t)p->world_size * per_rank * RT_TILE_W * RT_TILE_H;
-    dim3 blk(256), grd((unsigned)((elems + 255) / 256));
-    if (d_rgb_shards && d_rgb_frame)
+    size_t tiles = (size_t)p->world_size * per_rank;
+    dim3 blk(256), grd;
+    int vec;
+    if (d_rgb_shards && d_rgb_frame) {
+        untile_launch_shape(tiles, d_rgb_shards, d_rgb_frame, p->width, grd, vec);
         hipLaunchKernelGGL(k_untile<float>, grd, blk, 0, stream, d_rgb_shards, d_rgb_frame, p->width, p->height, tiles_x, total,
-                           per_rank, p->world_size, 0, p->world_size);
-    if (d_rgb8_shards && d_rgb8_frame)
+                           per_rank, p->world_size, 0, p->world_size, vec);
+    }
+    if (d_rgb8_shards && d_rgb8_frame) {
+        untile_launch_shape(tiles, d_rgb8_shards, d_rgb8_frame, p->width, grd, vec);
         hipLaunchKernelGGL(k_untile<uint8_t>, grd, blk, 0, stream, d_rgb8_shards, d_rgb8_frame, p->width, p->height, tiles_x,
-                           total, per_rank, p->world_size, 0, p->world_size);
+                           total, per_rank, p->world_size, 0, p->world_size, vec);
+    }
     RT_HIP(hipGetLastError());
     return RT_OK;
 }
@@ -1224,14 +1250,18 @@ extern "C" int rt_render(rt_ctx *ctx, const rt_render_params *p, float *rgb_line
     rc = rt_render_shard_device(ctx, p, d_tiles, d_tiles8);
     if (rc == RT_OK) {
         int tiles_x = (p->width + RT_TILE_W - 1) / RT_TILE_W;
-        size_t elems = (size_t)per_rank * RT_TILE_W * RT_TILE_H;
-        dim3 blk(256), grd((unsigned)((elems + 255) / 256));
-        if (d_tiles)
+        dim3 blk(256), grd;
+        int vec;
+        if (d_tiles) {
+            untile_launch_shape((size_t)per_rank, d_tiles, d_frame, p->width, grd, vec);
             hipLaunchKernelGGL(k_untile<float>, grd, blk, 0, ctx->stream, d_tiles, d_frame, p->width, p->height, tiles_x, total, per_rank,
-                               p->world_size, p->rank, 1);
-        if (d_tiles8)
+                               p->world_size, p->rank, 1, vec);
+        }
+        if (d_tiles8) {
+            untile_launch_shape((size_t)per_rank, d_tiles8, d_frame8, p->width, grd, vec);
             hipLaunchKernelGGL(k_untile<uint8_t>, grd, blk, 0, ctx->stream, d_tiles8, d_frame8, p->width, p->height, tiles_x, total,
-                               per_rank, p->world_size, p->rank, 1);
+                               per_rank, p->world_size, p->rank, 1, vec);
+        }
         hipError_t e = hipGetLastError();
         if (e == hipSuccess && rgb_linear) e = hipMemcpyAsync(rgb_linear, d_frame, frame_elems * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess && rgb8) e = hipMemcpyAsync(rgb8, d_frame8, frame_elems, hipMemcpyDeviceToHost, ctx->stream);

@@ -131,7 +131,14 @@ def test_sharded_render_reassembles_bitwise(gpu_ctx):
     order and de-interleaved by rt_untile_device, equals the single-rank frame bit for bit."""
     import torch
     ctx = gpu_ctx("teapot")
-    w, h = 200, 120  # 13 x 8 tiles: not divisible by the world sizes below
+    # 13 x 8 tiles: not divisible by the world sizes below; 200 wide: the last tile column sticks out and the
+    # 8-bit rows are not 16-byte aligned (byte-wise de-interleave), 208 wide: whole tiles, 16-byte pieces
+    for w, h in ((200, 120), (208, 120)):
+        _sharded_render_case(ctx, w, h)
+
+
+def _sharded_render_case(ctx, w, h):
+    import torch
     full, full8 = ctx.render(w, h, mode=rt.MODE_GRID, grid_m=2)
     for world in (2, 3, 8):
         p0 = ctx.params(w, h, mode=rt.MODE_GRID, grid_m=2, world_size=world)
