@@ -15,6 +15,8 @@ a CPU baseline (the oracle restatement of the reference's brute-force loop, time
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -22,8 +24,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 # algorithmic FP32 operations per unit of work (FMA = 2), used for roofline.achieved
-FLOPS = {"tri_tests": 71, "box_tests": 24, "gate_tests": 12 * 71, "quadric_tests": 95,
-         "plane_tests": 20, "shade_evals": 70, "tri_final": 60}
+FLOPS = {"tri_tests": 71, "box_tests": 24, "gate_tri_tests": 71, "quadric_tests": 95,
+         "plane_tests": 20, "shade_evals": 70}  # gate_tri_tests: the Box gate's triangle tests that were entered
 PEAK_FP32_TFLOPS = 157.3  # MI355X vector FP32 peak (256 CU x 2.4 GHz x 256 flop/clk)
 
 WORKLOADS = {
@@ -64,6 +66,70 @@ def cpu_baseline(preset, width, height, mode, grid_m, max_depth, budget_blocks=N
                       f"({len(o)} primary rays, {total} rays, {dt:.1f} s)"}
 
 
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: starts the N rank processes itself
+    (torch.distributed.run, one per GPU, rendezvous on 127.0.0.1) and returns their exit code.  Called
+    before this process has imported torch or touched the GPU; the parent only waits."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL between processes needs it on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
+def timed_steps(step, barrier, steps, warmup):
+    """The timing contract: `warmup` untimed steps, then exactly `steps` steps between two barriers."""
+    for _ in range(warmup):
+        step(None)
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        step(k)
+    barrier()
+    return time.perf_counter() - t0
+
+
+def stub_main(args, world, rank):
+    """The launcher, the rendezvous, the barriers and the max-over-ranks reduction of this script with a
+    step that needs no GPU (gloo): what tests/test_bench_launcher.py runs on a machine without one."""
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("gloo")
+    acc = torch.zeros(1, dtype=torch.float64)
+
+    def step(_k):
+        acc.add_(1.0)
+        time.sleep(0.002 * (rank + 1))  # ranks of unequal speed: the slowest decides
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    elapsed = timed_steps(step, barrier, args.steps, args.warmup)
+    t = torch.tensor([elapsed], dtype=torch.float64)
+    units = torch.tensor([float(acc) - args.warmup], dtype=torch.float64)
+    per_rank = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+    if world > 1:
+        dist.all_gather(per_rank, t.clone())
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(units, op=dist.ReduceOp.SUM)
+    else:
+        per_rank = [t.clone()]
+    if rank == 0:
+        print(json.dumps({"metric": "stub steps/s", "value": float(units) / float(t), "unit": "steps/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": float(t) / args.steps * 1e3,
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "none",
+                          "data": "synthetic", "config": {"workload": "stub"},
+                          "elapsed_per_rank_s": [float(x) for x in per_rank]}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -73,18 +139,28 @@ def main():
     ap.add_argument("--accel", default="lbvh", choices=["lbvh", "brute"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--float-frame", action="store_true", help="also produce the linear float frame")
+    ap.add_argument("--stub-step", action="store_true", help=argparse.SUPPRESS)  # launcher test without a GPU
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # not started by a launcher: start the ranks, before anything here touches the GPU
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)")
+    if args.stub_step:
+        return stub_main(args, world, rank)
 
     import torch
     import torch.distributed as dist
     import ray_tracer_amd as rt
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    n_dev = torch.cuda.device_count()  # (counting devices does not initialise the GPU runtime)
+    if n_dev < world or local_rank >= n_dev:
+        raise SystemExit(f"bench.py --gpus {world}: rank {rank} needs GPU {local_rank}, but this node has {n_dev} GPU(s); "
+                         "one GPU per rank is required")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the renderer has no CPU path")
     torch.cuda.set_device(local_rank)
@@ -109,36 +185,26 @@ def main():
     total_tiles = pipe.total_tiles
     dev = pipe.dev
 
-    def step(events=None):
-        pipe.submit(p, events)
+    evs = []
+
+    def step(k):
+        if k is None:
+            pipe.submit(p)
+        else:
+            evs.append((torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)))
+            pipe.submit(p, evs[-1])
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+        if not evs:  # between warm-up and the timed steps
+            ctx.reset_counters()
+            torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    ctx.reset_counters()
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    barrier()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(evs[k])
-    barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed = timed_steps(step, barrier, args.steps, args.warmup)
     c = ctx.counters()
-    rays_local = c.rays
     kernel_ms = sum(a.elapsed_time(b) for a, b in evs) / max(args.steps, 1)
-
-    tl = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev)
-    tr = torch.tensor([float(rays_local)], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(tl, op=dist.ReduceOp.MAX)
-        dist.all_reduce(tr, op=dist.ReduceOp.SUM)
-    elapsed, kernel_ms = float(tl[0]), float(tl[1])
-    rays_total = float(tr[0])
 
     # one extra frame with the counting kernel variant (outside the timed region) for the roofline
     ctx.reset_counters()
@@ -147,28 +213,53 @@ def main():
     pipe.submit(pc)
     torch.cuda.synchronize()
     cw = ctx.counters()
-    flops_local = (cw.tri_tests * FLOPS["tri_tests"] + cw.box_tests * FLOPS["box_tests"] +
-                   cw.gate_tests * FLOPS["gate_tests"] + cw.quadric_tests * FLOPS["quadric_tests"] +
-                   cw.plane_tests * FLOPS["plane_tests"] + cw.shade_evals * FLOPS["shade_evals"])
-    achieved_tflops = flops_local / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
+    count_names = ("tri_tests", "box_tests", "gate_tri_tests", "quadric_tests", "plane_tests", "shade_evals")
+    flops_local = sum(getattr(cw, n) * FLOPS[n] for n in count_names)
+
+    # every rank's figures on rank 0: [elapsed, kernel ms, rays, shadow queries run, flops of a launch, counts...]
+    mine = torch.tensor([elapsed, kernel_ms, float(c.rays), float(c.shadow_queries), float(flops_local)] +
+                        [float(getattr(cw, n)) for n in count_names] +
+                        [float(cw.rays), float(cw.gate_tests), float(c.rays - c.rays_shadow + c.shadow_queries)],
+                        dtype=torch.float64, device=dev)
+    rows = [torch.zeros_like(mine) for _ in range(world)]
+    if world > 1:
+        dist.all_gather(rows, mine)
+    else:
+        rows = [mine]
+    rows = torch.stack(rows).cpu().numpy()
 
     if rank == 0:
+        elapsed = float(rows[:, 0].max())  # the slowest rank decides
+        rays_total, shadow_queries = float(rows[:, 2].sum()), float(rows[:, 3].sum())
         ms_per_step = elapsed / args.steps * 1e3
         value = rays_total / elapsed / 1e6
-        traffic = None
+        # roofline of the render kernel: algorithmic flops of each rank's launch over that launch's duration, per GPU
+        per_rank_tflops = [float(r[4]) / (float(r[1]) * 1e-3) / 1e12 if r[1] > 0 else 0.0 for r in rows]
+        achieved_tflops = sum(per_rank_tflops) / world
+        counts = {n: int(rows[:, 5 + i].sum()) for i, n in enumerate(count_names)}
+        counts["rays"] = int(rows[:, 5 + len(count_names)].sum())
+        counts["gates"] = int(rows[:, 6 + len(count_names)].sum())
+        kernel_ms_max = float(rows[:, 1].max())
+        traffic = pmc_flops = None
         pmc_path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        kernel_names = ("k_render", "k_render_split<1>", "k_render_split<2>", "k_render_hybrid")
-        # the counter passes were made on the single-GPU launch of k_render: no figure for a rank's share
-        if world == 1 and c.render_variant == 0 and os.path.exists(pmc_path):
+        kernel_names = ("k_render", "k_render_split<1>", "k_render_split<2>", "k_render_hybrid", "k_render_queue")
+        # the counter passes were made on the single-GPU launch: no figure for a rank's share
+        if world == 1 and os.path.exists(pmc_path):
             try:
-                traffic = json.load(open(pmc_path)).get(args.workload)
+                rec = json.load(open(pmc_path)).get(args.workload)
+                if isinstance(rec, dict) and rec.get("kernel") == kernel_names[c.render_variant]:
+                    traffic, pmc_flops = rec.get("hbm_bytes"), rec.get("fp32_flops")
             except Exception:
-                traffic = None
+                traffic = pmc_flops = None
         out = {
             "metric": "Mrays/s (teapot.obj, 3840x2160, 16 spp)" if args.workload == "teapot_4k_16spp" else f"Mrays/s ({args.workload})",
             "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "ms_per_frame": ms_per_step, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            # one ray = one find_closest_hit of the reference (main.cpp:653, 718); a shadow ray whose query the kernel
+            # proved unnecessary (nothing can lie between the point and the light) is counted but was not traced
+            "rays": {"per_frame": rays_total / args.steps, "shadow_queries_executed_per_frame": shadow_queries / args.steps,
+                     "executed_Mrays_per_s": float(rows[:, 7 + len(count_names)].sum()) / elapsed / 1e6},
             "config": {"workload": args.workload, "preset": preset, "width": width, "height": height,
                        "samples_per_pixel": 1 if mode == 0 else 9 if mode == 1 else grid_m * grid_m,
                        "max_depth": max_depth, "accel": args.accel, "tiles": total_tiles,
@@ -178,13 +269,12 @@ def main():
                        "tree_build": "radix" if os.environ.get("RT_BUILD") == "radix" else "binned surface-area splits",
                        "render_kernel": kernel_names[c.render_variant]},
             "roofline": {"bound": "valu", "achieved": achieved_tflops, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved_tflops / PEAK_FP32_TFLOPS, "traffic": traffic,
-                         "kernel": kernel_names[c.render_variant], "kernel_ms": kernel_ms,
-                         "counts_per_launch": {"tri_tests": cw.tri_tests, "box_tests": cw.box_tests,
-                                               "gate_tests": cw.gate_tests, "quadric_tests": cw.quadric_tests,
-                                               "plane_tests": cw.plane_tests, "shade_evals": cw.shade_evals,
-                                               "rays": cw.rays},
-                         "tri_tests_per_s": cw.tri_tests / (kernel_ms * 1e-3) if kernel_ms > 0 else 0.0},
+                         "frac": achieved_tflops / PEAK_FP32_TFLOPS, "traffic": traffic, "pmc_flops": pmc_flops,
+                         "kernel": kernel_names[c.render_variant], "kernel_ms": kernel_ms_max,
+                         "kernel_ms_per_rank": [float(x) for x in rows[:, 1]],
+                         "achieved_per_rank": per_rank_tflops,
+                         "flops_per_unit": FLOPS, "counts_per_launch": counts,
+                         "tri_tests_per_s": (counts["tri_tests"] + counts["gate_tri_tests"]) / (kernel_ms_max * 1e-3) if kernel_ms_max > 0 else 0.0},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(preset, width, height, mode, grid_m, max_depth)

@@ -173,10 +173,14 @@ typedef struct {
     uint64_t rays_primary;   /* one ray = one find_closest_hit evaluation (main.cpp:653, 718) */
     uint64_t rays_shadow;
     uint64_t rays_secondary; /* reflection + refraction */
+    /* Shadow rays whose closest-hit query was run.  The others (rays_shadow - shadow_queries) were
+     * answered without one: nothing in the scene can lie between their origin and the light. */
+    uint64_t shadow_queries;
     /* the following are filled only when count_work was set */
     uint64_t tri_tests;   /* ray-triangle tests entered (mesh triangles)          */
     uint64_t box_tests;   /* ray-AABB slab tests (two per BVH node visited)        */
-    uint64_t gate_tests;  /* Box gates evaluated with the 12-triangle test         */
+    uint64_t gate_tests;  /* Box gates evaluated with the exact triangle test      */
+    uint64_t gate_tri_tests; /* triangle tests entered while evaluating those gates */
     uint64_t quadric_tests; /* sphere + cone tests */
     uint64_t plane_tests;
     uint64_t shade_evals; /* (hit, light) Phong evaluations                        */

@@ -102,8 +102,9 @@ class RenderParams(C.Structure):
 
 class Counters(C.Structure):
     _fields_ = [("rays_primary", C.c_uint64), ("rays_shadow", C.c_uint64),
-                ("rays_secondary", C.c_uint64), ("tri_tests", C.c_uint64), ("box_tests", C.c_uint64),
-                ("gate_tests", C.c_uint64), ("quadric_tests", C.c_uint64),
+                ("rays_secondary", C.c_uint64), ("shadow_queries", C.c_uint64),
+                ("tri_tests", C.c_uint64), ("box_tests", C.c_uint64),
+                ("gate_tests", C.c_uint64), ("gate_tri_tests", C.c_uint64), ("quadric_tests", C.c_uint64),
                 ("plane_tests", C.c_uint64), ("shade_evals", C.c_uint64), ("tex_fetches", C.c_uint64),
                 ("last_trace_ms", C.c_float), ("last_build_ms", C.c_float),
                 ("bvh_max_depth", C.c_int32), ("render_variant", C.c_int32)]

@@ -292,12 +292,12 @@ struct DevScene {
 
 // per-thread work counters; the counting variant is a separate template instantiation
 struct Work {
-    uint32_t rays_primary, rays_shadow, rays_secondary;
-    uint32_t tri, box, gate, quadric, plane, shade, tex;
+    uint32_t rays_primary, rays_shadow, rays_secondary, shadow_q;
+    uint32_t tri, box, gate, gate_tri, quadric, plane, shade, tex;
 };
 RT_HD void work_zero(Work &w) {
-    w.rays_primary = w.rays_shadow = w.rays_secondary = 0;
-    w.tri = w.box = w.gate = w.quadric = w.plane = w.shade = w.tex = 0;
+    w.rays_primary = w.rays_shadow = w.rays_secondary = w.shadow_q = 0;
+    w.tri = w.box = w.gate = w.gate_tri = w.quadric = w.plane = w.shade = w.tex = 0;
 }
 
 // ---------------------------------------------------------------- textures
@@ -785,7 +785,11 @@ RT_HD bool mesh_geom(const DevScene &S, const MeshHead &h, const DevMesh &m, v3 
         if (COUNT) wk.gate++;
         const f4 *gt = S.gate_tri + 3 * (size_t)h.gate_tri_offset;
         bool any = false;
-        for (int i = 0; i < 12; i++) any = any || tri_hits(gt, i, bo, bd);
+        for (int i = 0; i < 12; i++) {
+            if (any) break;
+            if (COUNT) wk.gate_tri++;
+            any = tri_hits(gt, i, bo, bd);
+        }
         if (!any) return false;
     }
     mh.t = best.t;
@@ -1230,6 +1234,7 @@ RT_HD void shade_lights(const DevScene &S, bool hit, int accel, Stack &stk, Work
         }
         if (hit) {
             wk.rays_shadow++;
+            if (query) wk.shadow_q++;
             if (!(cs.distance < light_r)) {
                 ShadeCtx sc;
                 unpark_shade<F>(stk, sc);

@@ -29,7 +29,7 @@ using namespace rtc;
 namespace {
 
 constexpr int kBlock = 256;
-constexpr int kNumCounters = 10;
+constexpr int kNumCounters = 12, kNumRayCounters = 4;  // the ray counters are kept by every kernel variant
 // The counters are kept in kCounterStripes copies, one 128-byte line each; a wave adds to the copy
 // its block and wave number select, and the host adds the copies up.  Hundreds of thousands of waves
 // adding to one address serialise in the L2's atomic unit (measured: 10 % of a 4 ms frame).
@@ -41,7 +41,7 @@ constexpr int kCounterStripes = 4096, kCounterStride = 16;
 // The mesh-only variant fits 96 registers and the quadric-only variant 80 without spilling (a sixth wave did not pay); the
 // others need more than 100.
 constexpr int render_waves(int features, bool count) {
-    return count ? 4 : features == F_MESH ? 5 : features == (F_QUADRIC | F_SECONDARY) ? 5 : 4;
+    return count ? 4 : features == 0 ? 8 : features == F_MESH ? 5 : features == (F_QUADRIC | F_SECONDARY) ? 5 : 4;
 }
 // k_render_split holds a round's radiance in LDS as well: with the larger parking area of the variants with
 // secondary rays only four blocks fit a compute unit
@@ -81,9 +81,9 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
 }
 
 __device__ __forceinline__ void flush_work(const Work &wk, unsigned long long *counters, bool count) {
-    unsigned long long vals[kNumCounters] = {wk.rays_primary, wk.rays_shadow, wk.rays_secondary, wk.tri, wk.box,
-                                             wk.gate, wk.quadric, wk.plane, wk.shade, wk.tex};
-    int n = count ? kNumCounters : 3;
+    unsigned long long vals[kNumCounters] = {wk.rays_primary, wk.rays_shadow, wk.rays_secondary, wk.shadow_q, wk.tri, wk.box,
+                                             wk.gate, wk.gate_tri, wk.quadric, wk.plane, wk.shade, wk.tex};
+    int n = count ? kNumCounters : kNumRayCounters;
     unsigned long long *mine = counters + (size_t)((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) % kCounterStripes) * kCounterStride;
     for (int i = 0; i < n; i++) {
         unsigned long long s = wave_sum(vals[i]);
@@ -1137,6 +1137,7 @@ extern "C" int rt_render_shard_device(rt_ctx *ctx, const rt_render_params *p, fl
     (variant == 0 ? (render_fn)k_render<FEATURES, COUNT>                                      \
                   : variant == 1 ? (render_fn)k_render_split<FEATURES, COUNT, 1> : (render_fn)k_render_split<FEATURES, COUNT, 2>)
     if (p->count_work) kernel = (render_fn)k_render<F_ALL, true>;
+    else if (f == 0) kernel = RT_PICK(0, false);
     else if ((f & ~F_MESH) == 0) kernel = RT_PICK(F_MESH, false);
     else if ((f & ~(F_MESH | F_SECONDARY)) == 0) kernel = RT_PICK(F_MESH | F_SECONDARY, false);
     else if ((f & ~(F_QUADRIC | F_SECONDARY)) == 0) kernel = RT_PICK(F_QUADRIC | F_SECONDARY, false);
@@ -1345,9 +1346,9 @@ extern "C" int rt_get_counters(rt_ctx *ctx, rt_counters *out) {
     for (int st = 0; st < kCounterStripes; st++)
         for (int i = 0; i < kNumCounters; i++) c[i] += all[(size_t)st * kCounterStride + i];
     std::memset(out, 0, sizeof *out);
-    out->rays_primary = c[0]; out->rays_shadow = c[1]; out->rays_secondary = c[2];
-    out->tri_tests = c[3]; out->box_tests = c[4]; out->gate_tests = c[5]; out->quadric_tests = c[6];
-    out->plane_tests = c[7]; out->shade_evals = c[8]; out->tex_fetches = c[9];
+    out->rays_primary = c[0]; out->rays_shadow = c[1]; out->rays_secondary = c[2]; out->shadow_queries = c[3];
+    out->tri_tests = c[4]; out->box_tests = c[5]; out->gate_tests = c[6]; out->gate_tri_tests = c[7]; out->quadric_tests = c[8];
+    out->plane_tests = c[9]; out->shade_evals = c[10]; out->tex_fetches = c[11];
     float ms = 0;
     if (hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) == hipSuccess) ctx->last_trace_ms = ms;
     out->last_trace_ms = ctx->last_trace_ms;
