@@ -220,7 +220,8 @@ int rt_build_accel(rt_ctx *ctx);
 
 /* Replaces main()'s pixel loop (main.cpp:1237-1273) including toneMapping (main.cpp:1184-1189) and
  * Image::setPixel quantisation (Image.cpp:35-39).  Host buffers, row-major 3*(y*w+x); either may be
- * NULL.  Blocking.  With world_size > 1 only this rank's tiles are written (others untouched). */
+ * NULL.  Blocking.  With world_size > 1 only this rank's tiles are written: the rest of each buffer
+ * comes back as the caller passed it, so the ranks of a frame can be rendered into one buffer in turn. */
 int rt_render(rt_ctx *ctx, const rt_render_params *p, float *rgb_linear, uint8_t *rgb8);
 
 /* Device-buffer variant for multi-GPU use: renders this rank's tiles into tile-major device

@@ -508,6 +508,30 @@ int orc_add_mesh_tris(orc_scene *s, int ntri, const float *pos, const float *nrm
     return finish_mesh(s, o, M, boxed);
 }
 
+/* A mesh from explicit fragments: triangle i has corners pos[i], normals nrm[i], texture coordinates
+ * uv[i] (NULL: zeros) and belongs to fragment fragsub[2i] as its fragsub[2i+1]-th triangle; two
+ * consecutive triangles of one fragment are a Diamond (main.cpp:425-479).  This is how the tests hand
+ * the oracle the faces that ANOTHER parser produced (the renderer's non-polluting OBJ mode). */
+int orc_add_mesh_frags(orc_scene *s, int ntri, const float *pos, const float *nrm, const float *uv,
+                       const int *fragsub, const float *M, const orc_material *mat, int boxed) {
+    object_t *o = new_object(K_MESH, mat);
+    o->mesh.ntri = ntri;
+    o->mesh.nfrag = 0;
+    o->mesh.tri = (tri_t *)calloc((size_t)(ntri > 0 ? ntri : 1), sizeof(tri_t));
+    for (int i = 0; i < ntri; i++) {
+        tri_t *t = &o->mesh.tri[i];
+        const float *p = pos + 9 * i, *n = nrm + 9 * i;
+        t->p1 = V3(p[0], p[1], p[2]); t->p2 = V3(p[3], p[4], p[5]); t->p3 = V3(p[6], p[7], p[8]);
+        t->n1 = V3(n[0], n[1], n[2]); t->n2 = V3(n[3], n[4], n[5]); t->n3 = V3(n[6], n[7], n[8]);
+        if (uv) { t->uv1.x = uv[6 * i]; t->uv1.y = uv[6 * i + 1]; t->uv2.x = uv[6 * i + 2]; t->uv2.y = uv[6 * i + 3];
+                  t->uv3.x = uv[6 * i + 4]; t->uv3.y = uv[6 * i + 5]; }
+        t->frag = fragsub[2 * i]; t->sub = fragsub[2 * i + 1];
+        if (t->frag + 1 > o->mesh.nfrag) o->mesh.nfrag = t->frag + 1;
+        t->mat = mat ? *mat : o->mat;
+    }
+    return finish_mesh(s, o, M, boxed);
+}
+
 /* ------------------------------------------------------------------ OBJ loader */
 
 typedef struct { v3 *a; int n, cap; } v3list;

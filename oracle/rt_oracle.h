@@ -86,6 +86,9 @@ int orc_add_mesh_obj(orc_scene *s, const char *path, const float *M, const orc_m
  * per-triangle material (NULL: all use mat). */
 int orc_add_mesh_tris(orc_scene *s, int ntri, const float *pos, const float *nrm,
                       const orc_material *mats, const float *M, const orc_material *mat, int boxed);
+/* explicit fragments: per triangle corners, normals, uv (or NULL) and (fragment, sub) ids */
+int orc_add_mesh_frags(orc_scene *s, int ntri, const float *pos, const float *nrm, const float *uv,
+                       const int *fragsub, const float *M, const orc_material *mat, int boxed);
 int orc_add_light(orc_scene *s, const float *pos, const float *color);
 void orc_set_ambient(orc_scene *s, const float *rgb);
 

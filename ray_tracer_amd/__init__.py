@@ -187,6 +187,7 @@ def host():
         L.rth_add_checker_texture.argtypes = [vp]
         L.rth_add_rainbow_texture.argtypes = [vp]
         L.rth_add_image_texture.argtypes = [vp, C.c_uint, C.c_uint, C.POINTER(vp)]
+        L.rth_add_image_texture_sized.argtypes = [vp, C.POINTER(C.c_uint), C.POINTER(C.c_uint), C.POINTER(vp)]
         L.rth_add_image_texture_files.argtypes = [vp, C.POINTER(C.c_char_p)]
         L.rth_add_sphere.argtypes = [vp, vp, C.POINTER(Material)]
         L.rth_add_plane.argtypes = [vp, vp, vp, C.POINTER(Material)]
@@ -304,8 +305,17 @@ class HostScene:
         """maps: five RGBA8 arrays [h, w, 4]: base, height, normal, occlusion, roughness."""
         maps = [np.ascontiguousarray(m, dtype=np.uint8) for m in maps]
         arr = (C.c_void_p * 5)(*[m.ctypes.data for m in maps])
-        hgt, w = maps[0].shape[:2]
-        return self.L.rth_add_image_texture(self.h, w, hgt, arr)
+        ws = (C.c_uint * 5)(*[m.shape[1] for m in maps])
+        hs = (C.c_uint * 5)(*[m.shape[0] for m in maps])
+        return self.L.rth_add_image_texture_sized(self.h, ws, hs, arr)
+
+    def add_image_texture_files(self, paths):
+        """paths: five PNG files: base, height, normal, occlusion, roughness."""
+        arr = (C.c_char_p * 5)(*[p.encode() for p in paths])
+        t = self.L.rth_add_image_texture_files(self.h, arr)
+        if t < 0:
+            raise RtError("image texture: " + self.L.rth_last_error(self.h).decode())
+        return t
 
     def add_sphere(self, M, mat):
         M = _f32(M)
@@ -392,10 +402,16 @@ class Context:
         return RenderParams(width, height, fov, mode, grid_m, max_depth, accel, rank, world_size,
                             int(count_work))
 
-    def render(self, width, height, want_rgb=True, want_rgb8=True, **kw):
+    def render(self, width, height, want_rgb=True, want_rgb8=True, into=None, **kw):
+        """into: (rgb, rgb8) arrays to render into instead of fresh ones (several ranks of one frame in turn)."""
         p = self.params(width, height, **kw)
-        rgb = np.zeros((height, width, 3), np.float32) if want_rgb else None
-        rgb8 = np.zeros((height, width, 3), np.uint8) if want_rgb8 else None
+        if into is not None:
+            rgb, rgb8 = into
+            assert rgb is None or (rgb.dtype == np.float32 and rgb.shape == (height, width, 3) and rgb.flags.c_contiguous)
+            assert rgb8 is None or (rgb8.dtype == np.uint8 and rgb8.shape == (height, width, 3) and rgb8.flags.c_contiguous)
+        else:
+            rgb = np.zeros((height, width, 3), np.float32) if want_rgb else None
+            rgb8 = np.zeros((height, width, 3), np.uint8) if want_rgb8 else None
         self._check(self.L.rt_render(self.h, C.byref(p), _ptr(rgb), _ptr(rgb8)), "rt_render")
         return rgb, rgb8
 

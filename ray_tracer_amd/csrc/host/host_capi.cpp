@@ -55,6 +55,21 @@ int rth_add_rainbow_texture(void *h) {
     s->holder.owned_textures.emplace_back(new RainbowTexture());
     return (int)s->holder.owned_textures.size() - 1;
 }
+// the same with a size per map (w[i] x hgt[i]); maps of unequal size are refused when the scene is flattened
+int rth_add_image_texture_sized(void *h, const unsigned w[5], const unsigned hgt[5], const uint8_t *const maps[5]) {
+    auto s = static_cast<HostScene *>(h);
+    PNG_Image_t *img[5];
+    for (int i = 0; i < 5; i++) {
+        auto im = std::make_unique<PNG_Image_t>();
+        im->width = w[i]; im->height = hgt[i];
+        if (maps[i]) im->data.assign(maps[i], maps[i] + (size_t)w[i] * hgt[i] * 4);
+        else im->data.assign((size_t)w[i] * hgt[i] * 4, 0);
+        img[i] = im.get();
+        s->holder.owned_images.push_back(std::move(im));
+    }
+    s->holder.owned_textures.emplace_back(new ImageTexture(*img[0], *img[1], *img[2], *img[3], *img[4]));
+    return (int)s->holder.owned_textures.size() - 1;
+}
 // five RGBA8 maps (base, height, normal, occlusion, roughness) of w*h texels each, copied
 int rth_add_image_texture(void *h, unsigned w, unsigned hgt, const uint8_t *const maps[5]) {
     auto s = static_cast<HostScene *>(h);
@@ -80,6 +95,12 @@ int rth_add_image_texture_files(void *h, const char *const paths[5]) {
         img[i] = im.get();
         s->holder.owned_images.push_back(std::move(im));
     }
+    for (int i = 2; i < 5; i++)  // the sampled maps (base colour, normal, occlusion, roughness) share one size; the height map is never read
+        if (img[i]->width != img[0]->width || img[i]->height != img[0]->height) {
+            s->err = std::string(paths[i]) + " is " + std::to_string(img[i]->width) + "x" + std::to_string(img[i]->height) + " but " + paths[0] +
+                     " is " + std::to_string(img[0]->width) + "x" + std::to_string(img[0]->height) + ": the sampled maps of an image texture must have one size";
+            return -1;
+        }
     s->holder.owned_textures.emplace_back(new ImageTexture(*img[0], *img[1], *img[2], *img[3], *img[4]));
     return (int)s->holder.owned_textures.size() - 1;
 }

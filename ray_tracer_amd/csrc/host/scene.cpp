@@ -105,6 +105,7 @@ void FlatScene::finish() {
 namespace {
 struct Flattener {
     FlatScene &fs;
+    std::string err;  // first problem found while lowering (checked by Scene::flatten)
     explicit Flattener(FlatScene &f) : fs(f) {}
 
     int texture(const Texture *t) {
@@ -114,6 +115,21 @@ struct Flattener {
         rt_texture rt{};
         rt.kind = t->kind();
         if (auto it = dynamic_cast<const ImageTexture *>(t)) {
+            // The description carries one width x height for the four sampled maps, and the upload reads
+            // width * height texels from each.  The reference samples every map with its own size
+            // (Textures.cpp:27-30); maps of unequal size are refused instead of being read out of bounds.
+            const PNG_Image_t *maps[4] = {&it->base_color, &it->normals_map, &it->ambient_occlusion_map, &it->roughness_map};
+            const char *names[4] = {"base colour", "normal", "occlusion", "roughness"};
+            for (int k = 0; k < 4; k++) {
+                const PNG_Image_t &m = *maps[k];
+                if (m.width != maps[0]->width || m.height != maps[0]->height || m.data.size() != (size_t)m.width * m.height * 4) {
+                    if (err.empty())
+                        err = std::string("image texture: the ") + names[k] + " map is " + std::to_string(m.width) + "x" + std::to_string(m.height) +
+                              " (" + std::to_string(m.data.size()) + " bytes) but the base colour map is " + std::to_string(maps[0]->width) + "x" +
+                              std::to_string(maps[0]->height) + "; the four sampled maps must have one size";
+                    return -1;
+                }
+            }
             rt.width = it->base_color.width;
             rt.height = it->base_color.height;
             rt.base_color = it->base_color.data.data();
@@ -223,6 +239,7 @@ bool Scene::flatten(FlatScene &out, std::string &err) const {
         out.objects.push_back(ro);
     }
     if (out.materials.empty()) f.material(Material());
+    if (!f.err.empty()) { err = f.err; return false; }
     for (auto l : lights) {
         out.light_pos.push_back(l->position.x); out.light_pos.push_back(l->position.y); out.light_pos.push_back(l->position.z);
         out.light_color.push_back(l->color.x); out.light_color.push_back(l->color.y); out.light_color.push_back(l->color.z);

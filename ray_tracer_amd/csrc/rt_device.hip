@@ -544,6 +544,7 @@ struct rt_ctx {
     hipStream_t stream = nullptr;      // the stream in use
     hipStream_t own_stream = nullptr;  // created with the context
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool trace_timed = false;  // ev0 / ev1 were recorded around a render launch (not around a build, and not never)
     std::string err;
     bool uploaded = false, built = false;
     std::vector<void *> allocs;  // everything owned by the current scene
@@ -724,15 +725,16 @@ extern "C" int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *sc) {
     if ((rc = dev_alloc(ctx, &ctx->d_tri_frag, nt, sc->tri_frag))) return rc;
     if ((rc = dev_alloc(ctx, &ctx->d_tri_sub, nt, sc->tri_sub))) return rc;
 
-    // textures
+    // textures (the interleaved texels are staged in host vectors that live until the stream has been synchronised below)
     std::vector<DevTexture> tex(sc->n_textures);
+    std::vector<std::vector<u4>> staged_texels(sc->n_textures);
     for (int i = 0; i < sc->n_textures; i++) {
         const rt_texture &t = sc->textures[i];
         tex[i].kind = t.kind; tex[i].w = t.width; tex[i].h = t.height; tex[i].pad = 0;
         tex[i].texels = nullptr;
         for (int k = 0; k < 3; k++) tex[i].pad2[k] = nullptr;
         if (t.kind == RT_TEX_IMAGE) {
-            std::vector<u4> texels;
+            std::vector<u4> &texels = staged_texels[i];
             interleave_texture(t, texels);
             u4 *d;
             if ((rc = dev_alloc(ctx, &d, texels.size(), texels.data()))) return rc;
@@ -942,6 +944,9 @@ extern "C" int rt_build_accel(rt_ctx *ctx) {
     hipError_t e = hipMemcpyAsync(d_bounds, bounds.data(), bounds.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
     if (e != hipSuccess) { cleanup(); return fail(ctx, RT_ERR_HIP, hipGetErrorString(e)); }
 
+    std::vector<int32_t> iota(max_n);  // outlives every copy queued from it
+    for (int k = 0; k < max_n; k++) iota[k] = k;
+    std::vector<SahJob> first_jobs(ctx->meshes.size());
     (void)hipEventRecord(ctx->ev0, ctx->stream);
     for (size_t i = 0; i < ctx->meshes.size(); i++) {
         const DevMesh &m = ctx->meshes[i];
@@ -964,11 +969,9 @@ extern "C" int rt_build_accel(rt_ctx *ctx) {
                 hipLaunchKernelGGL(k_children, dim3((n + 255) / 256), blk, 0, ctx->stream, d_keys, n, d_c0, d_c1);
             } else {
                 // top-down, one launch per level; the number of jobs of the next level comes back each time
-                std::vector<int32_t> iota(n);
-                for (int k = 0; k < n; k++) iota[k] = k;
-                SahJob first_job = {0, n - 1, -1, 0};
+                first_jobs[i] = SahJob{0, n - 1, -1, 0};
                 e = hipMemcpyAsync(d_idx[0], iota.data(), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream);
-                if (e == hipSuccess) e = hipMemcpyAsync(d_jobs[0], &first_job, sizeof first_job, hipMemcpyHostToDevice, ctx->stream);
+                if (e == hipSuccess) e = hipMemcpyAsync(d_jobs[0], &first_jobs[i], sizeof(SahJob), hipMemcpyHostToDevice, ctx->stream);
                 int n_jobs = 1, cur = 0;
                 for (int level = 0; e == hipSuccess && n_jobs > 0; level++, cur ^= 1) {
                     if (level > kSahDepthLimit + 40) { e = hipErrorUnknown; break; }  // cannot happen: the height is bounded
@@ -993,6 +996,7 @@ extern "C" int rt_build_accel(rt_ctx *ctx) {
         }
     }
     (void)hipEventRecord(ctx->ev1, ctx->stream);
+    ctx->trace_timed = false;
     if (e == hipSuccess) e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e == hipSuccess)  // the roots
@@ -1186,6 +1190,7 @@ extern "C" int rt_render_shard_device(rt_ctx *ctx, const rt_render_params *p, fl
         ctx->tune.recorded[measure] = true;
     }
     RT_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+    ctx->trace_timed = true;
     return RT_OK;
 }
 
@@ -1239,14 +1244,19 @@ extern "C" int rt_render(rt_ctx *ctx, const rt_render_params *p, float *rgb_line
     uint8_t *d_tiles8 = nullptr, *d_frame8 = nullptr;
     std::vector<void *> tmp;
     auto cleanup = [&]() { for (void *q : tmp) (void)hipFree(q); };
-    auto alloc = [&](void **ptr, size_t bytes) -> bool {
+    // seed: what the device buffer starts from.  A rank that shares the frame with others (world_size > 1) starts
+    // from the caller's frame, so that the tiles of the other ranks come back as they went in.
+    auto alloc = [&](void **ptr, size_t bytes, const void *seed) -> bool {
         if (hipMalloc(ptr, bytes) != hipSuccess) return false;
         tmp.push_back(*ptr);
+        if (seed) return hipMemcpyAsync(*ptr, seed, bytes, hipMemcpyHostToDevice, ctx->stream) == hipSuccess;
         return hipMemsetAsync(*ptr, 0, bytes, ctx->stream) == hipSuccess;
     };
+    const bool shared = p->world_size > 1;
     bool ok = true;
-    if (rgb_linear) ok = ok && alloc((void **)&d_tiles, shard_elems * sizeof(float)) && alloc((void **)&d_frame, frame_elems * sizeof(float));
-    if (rgb8) ok = ok && alloc((void **)&d_tiles8, shard_elems) && alloc((void **)&d_frame8, frame_elems);
+    if (rgb_linear) ok = ok && alloc((void **)&d_tiles, shard_elems * sizeof(float), nullptr) &&
+                         alloc((void **)&d_frame, frame_elems * sizeof(float), shared ? rgb_linear : nullptr);
+    if (rgb8) ok = ok && alloc((void **)&d_tiles8, shard_elems, nullptr) && alloc((void **)&d_frame8, frame_elems, shared ? rgb8 : nullptr);
     if (!ok) { cleanup(); return fail(ctx, RT_ERR_HIP, "rt_render: device allocation failed"); }
     rc = rt_render_shard_device(ctx, p, d_tiles, d_tiles8);
     if (rc == RT_OK) {
@@ -1268,7 +1278,7 @@ extern "C" int rt_render(rt_ctx *ctx, const rt_render_params *p, float *rgb_line
         if (e == hipSuccess && rgb8) e = hipMemcpyAsync(rgb8, d_frame8, frame_elems, hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) rc = fail(ctx, RT_ERR_HIP, std::string("rt_render: ") + hipGetErrorString(e));
-        else (void)hipEventElapsedTime(&ctx->last_trace_ms, ctx->ev0, ctx->ev1);
+        else if (ctx->trace_timed) (void)hipEventElapsedTime(&ctx->last_trace_ms, ctx->ev0, ctx->ev1);
     }
     cleanup();
     return rc;
@@ -1350,7 +1360,7 @@ extern "C" int rt_get_counters(rt_ctx *ctx, rt_counters *out) {
     out->tri_tests = c[4]; out->box_tests = c[5]; out->gate_tests = c[6]; out->gate_tri_tests = c[7]; out->quadric_tests = c[8];
     out->plane_tests = c[9]; out->shade_evals = c[10]; out->tex_fetches = c[11];
     float ms = 0;
-    if (hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) == hipSuccess) ctx->last_trace_ms = ms;
+    if (ctx->trace_timed && hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) == hipSuccess) ctx->last_trace_ms = ms;
     out->last_trace_ms = ctx->last_trace_ms;
     out->last_build_ms = ctx->last_build_ms;
     out->bvh_max_depth = ctx->bvh_max_depth;

@@ -75,6 +75,8 @@ def lib():
         L.orc_add_mesh_obj.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         L.orc_add_mesh_tris.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_add_mesh_frags.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_void_p, C.c_int]
         L.orc_add_light.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_num_objects.argtypes = [C.c_void_p]
         L.orc_num_lights.argtypes = [C.c_void_p]

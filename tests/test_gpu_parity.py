@@ -157,10 +157,17 @@ def _sharded_render_case(ctx, w, h):
         assert np.array_equal(frame8.cpu().numpy(), full8)
         # the host-side restatement of the tile rule agrees with the kernels
         assert np.array_equal(tiling.frame_from_shards(shards.cpu().numpy(), w, h), full, equal_nan=True)
-        # rt_render with world_size > 1 writes only this rank's tiles
-        part, _ = ctx.render(w, h, mode=rt.MODE_GRID, grid_m=2, rank=1, world_size=world)
-        mine = tiling.frame_from_shards(np.stack([tiling.shard_from_frame(full, r, world) * (r == 1) for r in range(world)]), w, h)
-        assert np.array_equal(part, mine, equal_nan=True)
+        # rt_render with world_size > 1 writes only this rank's tiles: the rest of the caller's buffers is left as it was
+        part, part8 = np.full((h, w, 3), -7.0, np.float32), np.full((h, w, 3), 201, np.uint8)
+        ctx.render(w, h, into=(part, part8), mode=rt.MODE_GRID, grid_m=2, rank=1, world_size=world)
+        is_mine = tiling.frame_from_shards(np.stack([np.full_like(tiling.shard_from_frame(full, r, world), float(r == 1)) for r in range(world)]), w, h) == 1
+        assert np.array_equal(part[is_mine], full[is_mine], equal_nan=True) and (part[~is_mine] == -7.0).all()
+        assert np.array_equal(part8[is_mine], full8[is_mine]) and (part8[~is_mine] == 201).all()
+        # ... so that the ranks of a frame can be composited into one host buffer, one after the other
+        for r in range(world):
+            if r != 1:
+                ctx.render(w, h, into=(part, part8), mode=rt.MODE_GRID, grid_m=2, rank=r, world_size=world)
+        assert np.array_equal(part, full, equal_nan=True) and np.array_equal(part8, full8)
 
 
 def test_full_size_properties(gpu_ctx):

@@ -192,3 +192,30 @@ def test_png_writer_round_trips_through_the_decoder(tmp_path):
         assert kinds[0] == b"IHDR" and kinds[-1] == b"IEND"
         raw = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(h, 1 + 3 * w)
         assert (raw[:, 0] == 0).all() and np.array_equal(raw[:, 1:].reshape(h, w, 3), img)
+
+
+def test_image_texture_maps_of_unequal_size_are_refused(tmp_path):
+    """The reference samples every map of an ImageTexture with that map's own size (Textures.cpp:27-30); the scene
+    description carries one size for the four sampled maps, so unequal ones are an error, not an over-read."""
+    big = np.full((8, 8, 4), 200, np.uint8)
+    small = np.full((4, 4, 4), 100, np.uint8)
+    sc = rt.HostScene()
+    tex = sc.add_image_texture([big, big, big, small, big])  # the occlusion map is smaller
+    sc.add_plane((0, -1, 0), (0, 1, 0), rt.Material(texture=tex))
+    sc.add_light((0, 5, 0), 1.0)
+    with pytest.raises(rt.RtError, match="occlusion map is 4x4"):
+        sc.flatten()
+    # the height map (never sampled, not uploaded) may have any size
+    ok = rt.HostScene()
+    tex = ok.add_image_texture([big, small, big, big, big])
+    ok.add_plane((0, -1, 0), (0, 1, 0), rt.Material(texture=tex))
+    d = ok.flatten().contents
+    assert d.n_textures == 1 and d.textures[0].width == 8 and d.textures[0].height == 8
+    # the same check on files
+    paths = []
+    for name, arr in (("base", big), ("height", big), ("normal", small), ("occ", big), ("rough", big)):
+        path = str(tmp_path / f"{name}.png")
+        rt.write_png(path, np.ascontiguousarray(arr[:, :, :3]))
+        paths.append(path)
+    with pytest.raises(rt.RtError, match="must have one size"):
+        rt.HostScene().add_image_texture_files(paths)
