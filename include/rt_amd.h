@@ -150,7 +150,14 @@ typedef struct {
     int32_t rank;      /* this context renders the tiles t with t % world_size == rank */
     int32_t world_size;
     int32_t count_work; /* non-zero: also count intersection tests (slower kernel variant) */
+    int32_t kernel;     /* RT_KERNEL_*: which render kernel; they all write the same pixels */
 } rt_render_params;
+
+/* RT_KERNEL_AUTO picks by a fixed rule (scenes with meshes and >= 4 taps per pixel: PER_TILE, else PIXEL).
+ * PIXEL: one lane per pixel, a block per tile.  SPLIT / SPLIT2: a pixel's taps spread over the waves of a
+ * block (a quadrant / half a quadrant per block).  PER_TILE: PIXEL or SPLIT per tile, by the tile's time in
+ * the previous frame.  QUEUE: persistent blocks taking tiles and quadrants from a work list, longest first. */
+enum { RT_KERNEL_AUTO = 0, RT_KERNEL_PIXEL = 1, RT_KERNEL_SPLIT = 2, RT_KERNEL_SPLIT2 = 3, RT_KERNEL_PER_TILE = 4, RT_KERNEL_QUEUE = 5 };
 
 #define RT_TILE_W 16
 #define RT_TILE_H 16
@@ -188,10 +195,7 @@ typedef struct {
     float last_trace_ms;  /* device time of the last trace kernel (HIP events)     */
     float last_build_ms;  /* device time of the last rt_build_accel                */
     int32_t bvh_max_depth;
-    int32_t render_variant; /* kernel of the last render launch: 0 one lane per pixel; 1, 2 a pixel's taps spread
-                               over the waves of a block, with one or two taps per wave at a time; 3 either way
-                               per tile, by the tile's time in the frame before (same pixels from all of them;
-                               the fastest is found by timing each once) */
+    int32_t render_variant; /* kernel of the last render launch, as RT_KERNEL_* - 1 */
 } rt_counters;
 
 /* Create / destroy a context on GPU `device` (a HIP device ordinal). */

@@ -23,6 +23,8 @@ ACCEL_LBVH, ACCEL_BRUTE = 0, 1
 TILE = 16
 MAX_DEPTH = 16
 OBJ_SPHERE, OBJ_PLANE, OBJ_CONE, OBJ_MESH = 0, 1, 2, 3
+KERNEL_AUTO, KERNEL_PIXEL, KERNEL_SPLIT, KERNEL_SPLIT2, KERNEL_PER_TILE, KERNEL_QUEUE = range(6)
+KERNEL_NAMES = ("k_render", "k_render_split<1>", "k_render_split<2>", "k_render_hybrid", "k_render_queue")  # by Counters.render_variant
 
 
 class RtError(RuntimeError):
@@ -97,7 +99,7 @@ class SceneDesc(C.Structure):
 class RenderParams(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("fov", C.c_float), ("mode", C.c_int32),
                 ("grid_m", C.c_int32), ("max_depth", C.c_int32), ("accel", C.c_int32),
-                ("rank", C.c_int32), ("world_size", C.c_int32), ("count_work", C.c_int32)]
+                ("rank", C.c_int32), ("world_size", C.c_int32), ("count_work", C.c_int32), ("kernel", C.c_int32)]
 
 
 class Counters(C.Structure):
@@ -398,9 +400,9 @@ class Context:
 
     @staticmethod
     def params(width, height, fov=90.0, mode=MODE_REF_1SPP, grid_m=1, max_depth=8, accel=ACCEL_LBVH,
-               rank=0, world_size=1, count_work=False):
+               rank=0, world_size=1, count_work=False, kernel=KERNEL_AUTO):
         return RenderParams(width, height, fov, mode, grid_m, max_depth, accel, rank, world_size,
-                            int(count_work))
+                            int(count_work), kernel)
 
     def render(self, width, height, want_rgb=True, want_rgb8=True, into=None, **kw):
         """into: (rgb, rgb8) arrays to render into instead of fresh ones (several ranks of one frame in turn)."""

@@ -46,7 +46,7 @@ constexpr int render_waves(int features, bool count) {
 // k_render_split holds a round's radiance in LDS as well: with the larger parking area of the variants with
 // secondary rays only four blocks fit a compute unit
 constexpr int split_waves(int features, bool count) { return (features & F_SECONDARY) ? 4 : render_waves(features, count); }
-constexpr int kRenderVariants = 4;  // k_render, k_render_split<PH = 1>, k_render_split<PH = 2>, k_render_hybrid
+constexpr int kVariantQueue = 4;     // k_render_queue
 constexpr int kWavesPerBlock = kBlock / 64;
 constexpr int kStackWords = 3 * kStackDepth;
 // The packet traversal keeps ONE stack per wave: entries of (node, 64-bit lane mask), three LDS
@@ -345,8 +345,9 @@ struct TapSlice {  // a trace_loop source: taps [k, k_end) of one pixel
     int col, row;           // GRID: k = row * grid_m + col
     const float *grid_off;  // GRID: the block's table of grid_offset(a, grid_m, cam.s)
     float wt;
-    float *slots;  // this lane's column of the LDS array [kRoundTaps][3][pixels of the block]
+    float *slots;  // this lane's column of the LDS array [kRoundTaps][3][pixels of the block]; nullptr: sum into `color` at once
     int stride;    // pixels of the block
+    v3 color;      // the pixel's running sum when the lane traces all its taps itself (slots == nullptr)
     __device__ bool next(v3 &ro, v3 &rd) {
         if (k >= k_end) return false;
         ro = V3(0, 0, 0);
@@ -361,11 +362,70 @@ struct TapSlice {  // a trace_loop source: taps [k, k_end) of one pixel
         return true;
     }
     __device__ void done(v3 r) {
+        if (slots == nullptr) {  // (wave-uniform)
+            color = mode == RT_MODE_REF_1SPP ? r : color + r * wt;
+            return;
+        }
         float *p = slots + (k - 1 - base) * 3 * stride;
         p[0] = r.x; p[stride] = r.y; p[2 * stride] = r.z;
     }
     __device__ rt_hit_record *first_hit() { return nullptr; }
 };
+
+// One work item of k_render_queue by one block, in one body for both kinds (two inlined bodies cost registers).
+// part < 0: the whole local tile, each wave a quadrant, each lane a pixel with all its taps, summed in registers as the
+// taps finish.  part = 0..3: that quadrant alone, the taps of its pixels spread over the four waves in rounds of
+// kRoundTaps and summed in tap order through LDS (tap_lds: kRoundTaps * 3 * 64 floats), as render_tile_part does.
+template <int F>
+__device__ __forceinline__ void render_item(const DevScene &S, const RenderArgs &a, int local, int part, WaveStack &stk, const float *grid_off,
+                                            float *tap_lds, float *rgb_tiles, uint8_t *rgb8_tiles, Work &wk) {
+    const bool whole = part < 0;  // (block-uniform)
+    const int tile = local * a.world_size + a.rank;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int quad = whole ? wave : part;
+    const int px = (quad & 1) * 8 + (lane & 7), py = (quad >> 1) * 8 + (lane >> 3);
+    const int i = (tile % a.tiles_x) * RT_TILE_W + px, j = (tile / a.tiles_x) * RT_TILE_H + py;
+    const bool inside = tile < a.tiles_total && i < a.width && j < a.height;
+    const int taps = taps_of(a.mode, a.grid_m);
+    const int round_taps = whole ? taps : kRoundTaps;
+    v3 color = V3(0, 0, 0);
+    for (int base = 0; base < taps; base += round_taps) {
+        const int n = taps - base < round_taps ? taps - base : round_taps;
+        const int chunk = whole ? n : (n + 3) / 4, slot = whole ? 0 : wave;
+        TapSlice src;
+        src.cam = a.cam; src.mode = a.mode; src.grid_m = a.grid_m; src.i = i; src.j = j; src.base = base; src.wt = 1.0f;
+        src.k = base + (slot * chunk < n ? slot * chunk : n);
+        src.k_end = base + ((slot + 1) * chunk < n ? (slot + 1) * chunk : n);
+        src.col = src.k % a.grid_m; src.row = src.k / a.grid_m; src.grid_off = grid_off;
+        src.slots = whole ? nullptr : tap_lds + lane;
+        src.stride = 64;
+        src.color = color;
+        if (inside && src.k < src.k_end) trace_loop<F, false>(S, a.max_depth, a.accel, stk, wk, src);
+        color = src.color;
+        if (!whole) {
+            __syncthreads();
+            if (wave == 0 && inside) {
+                for (int t = 0; t < n; t++) {
+                    const float *p = tap_lds + t * 3 * 64 + lane;
+                    v3 r = V3(p[0], p[64], p[128]);
+                    color = a.mode == RT_MODE_REF_1SPP ? r : color + r * tap_weight(a.mode, base + t);
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (whole || wave == 0) {
+        if (a.mode != RT_MODE_REF_1SPP) color = color / (a.mode == RT_MODE_REF_AA9 ? 16.f : (float)taps);
+        size_t p = ((size_t)local * (RT_TILE_W * RT_TILE_H) + (size_t)py * RT_TILE_W + px) * 3;
+        if (rgb_tiles) { rgb_tiles[p] = color.x; rgb_tiles[p + 1] = color.y; rgb_tiles[p + 2] = color.z; }
+        if (rgb8_tiles) {
+            v3 t = tone_map(color);
+            rgb8_tiles[p] = inside ? quantise(t.x) : 0;
+            rgb8_tiles[p + 1] = inside ? quantise(t.y) : 0;
+            rgb8_tiles[p + 2] = inside ? quantise(t.z) : 0;
+        }
+    }
+}
 
 // Part `part` (of 4 * PH) of local tile `local` by one block; tap_lds: kRoundTaps * 3 * (64 / PH) floats of LDS.
 template <int F, bool COUNT, int PH>
@@ -392,6 +452,7 @@ __device__ __forceinline__ void render_tile_part(const DevScene &S, const Render
         src.col = src.k % a.grid_m; src.row = src.k / a.grid_m; src.grid_off = grid_off;  // (one division per round, not per tap)
         src.slots = tap_lds + pl;
         src.stride = PX;
+        src.color = V3(0, 0, 0);
         if (inside && src.k < src.k_end) trace_loop<F, COUNT>(S, a.max_depth, a.accel, stk, wk, src);
         __syncthreads();
         if (wave == 0 && phase == 0 && inside) {
@@ -436,13 +497,13 @@ __global__ __launch_bounds__(kBlock, split_waves(F, COUNT)) void k_render_split(
 // The heavy tiles then no longer decide the length of a short launch (one rank's share of a frame), and the
 // light ones keep the cheaper kernel.  One block of every tile leaves the tile's time for the next frame in
 // cost_out (another array than cost_in: the four blocks of a tile must read the same value).
-struct TileCosts { const uint32_t *cost_in; uint32_t *cost_out; uint32_t threshold; };
+struct TileCosts { const uint32_t *cost_in; uint32_t *cost_out; const uint32_t *threshold; };  // threshold: written by k_tile_threshold just before
 template <int F>
 __global__ __launch_bounds__(kBlock, split_waves(F, false)) void k_render_hybrid(DevScene S, RenderArgs a, float *rgb_tiles,
                                                                                   uint8_t *rgb8_tiles, unsigned long long *counters,
                                                                                   TileCosts tc) {
     const int local = blockIdx.x >> 2, quad = blockIdx.x & 3;
-    const bool heavy = tc.cost_in[local] > tc.threshold;  // the same for the tile's four blocks
+    const bool heavy = tc.cost_in[local] > *tc.threshold;  // the same for the tile's four blocks
     // Which of the four blocks takes a light tile is scattered by a hash of the tile: blocks are handed to the
     // XCDs and their compute units in turn, and a regular pattern of working and leaving blocks keeps most of
     // them idle (measured: 12.7 ms with always the first block, 12.1 ms with a rotation, 3.3 ms scattered).
@@ -464,6 +525,157 @@ __global__ __launch_bounds__(kBlock, split_waves(F, false)) void k_render_hybrid
         unsigned long long dt = (wall_clock64() - t0) * (heavy ? 4ull : 1ull);  // a quadrant's time stands for a quarter of the tile's
         tc.cost_out[local] = dt > 0xffffffffull ? 0xffffffffu : (uint32_t)dt;
     }
+}
+
+// ---- persistent blocks fed from a work queue
+//
+// The launch has as many blocks as the GPU keeps resident; each block takes work items from a list until the
+// list is empty (one atomic per item).  An item is a whole 16x16 tile (each wave a quadrant, each lane a pixel,
+// all taps: the cheapest way to render a tile) or, for a tile that took long in the previous frame, one of its
+// four quadrants with the pixel's taps spread over the block's waves (a quarter as long).  k_plan_tiles builds
+// the list before every frame from the tiles' times in the previous one: the quadrants of the heavy tiles first,
+// longest first, then the light tiles in frame order.  With the long items handed out first and the short ones
+// last, the blocks finish together: the end of a launch no longer waits for the block that happened to get a
+// heavy tile late, which is what limits a short launch (one GPU's share of a frame on a node of eight).
+// Which tiles count as heavy changes only who renders a pixel, never its value.
+//
+// Queue memory (`QueueMem`, one per context, or the library's static array for the entry point that may not
+// allocate): header, two arrays of tile times used in turn, the item list.
+struct QueueHeader {
+    uint32_t next;       // next item to hand out
+    uint32_t n_items;
+    uint32_t n_heavy;    // heavy tiles in this frame's list
+    uint32_t threshold;  // ticks of the 100 MHz clock above which a tile counted as heavy
+    uint32_t pad[60];
+};
+static_assert(sizeof(QueueHeader) == 256, "QueueHeader layout");
+constexpr uint32_t kItemQuadrant = 0x80000000u;  // item = tile | quadrant << 28 | kItemQuadrant
+constexpr int kPlanThreads = 1024, kCostBuckets = 32;
+
+// The threshold of k_render_hybrid, one block: 1.5 times the mean of the tiles' known times in the previous frame
+// (a tile of unknown time, 0xffffffff, is above any threshold and does not enter the mean).
+__global__ __launch_bounds__(kPlanThreads) void k_tile_threshold(QueueHeader *q, const uint32_t *cost_in, int n_tiles, uint32_t forced_threshold,
+                                                                 int use_forced) {
+    __shared__ unsigned long long s_sum[kPlanThreads / 64], s_cnt[kPlanThreads / 64];
+    const int t = threadIdx.x;
+    unsigned long long sum = 0, cnt = 0;
+    for (int i = t; i < n_tiles; i += kPlanThreads) { uint32_t c = cost_in[i]; if (c != 0xffffffffu) { sum += c; cnt++; } }
+    sum = wave_sum(sum); cnt = wave_sum(cnt);
+    if ((t & 63) == 0) { s_sum[t >> 6] = sum; s_cnt[t >> 6] = cnt; }
+    __syncthreads();
+    if (t == 0) {
+        unsigned long long total = 0, n = 0;
+        for (int w = 0; w < kPlanThreads / 64; w++) { total += s_sum[w]; n += s_cnt[w]; }
+        unsigned long long th = n ? total * 3ull / (2ull * n) : 0ull;
+        q->threshold = use_forced ? forced_threshold : (th > 0xfffffffeull ? 0xfffffffeu : (uint32_t)th);
+    }
+}
+
+// One block.  cost_in: last frame's time per tile (0xffffffff: unknown, counts as heavy); cost_out: zeroed here,
+// filled by the render kernel.  slots: blocks of the render launch.
+__global__ __launch_bounds__(kPlanThreads) void k_plan_tiles(QueueHeader *q, const uint32_t *cost_in, uint32_t *cost_out, uint32_t *items,
+                                                             int n_tiles, int slots, uint32_t forced_threshold, int use_forced) {
+    __shared__ unsigned long long s_sum[kPlanThreads / 64];
+    __shared__ uint32_t s_scan[kPlanThreads];
+    __shared__ uint32_t s_bucket[kCostBuckets], s_bucket_base[kCostBuckets];
+    __shared__ uint32_t s_threshold, s_heavy;
+    const int t = threadIdx.x;
+    // the threshold: a sixteenth of the launch's expected length (sum of the known times / slots), so that whatever
+    // is handed out last is short against the whole; tiles of unknown time do not enter the sum
+    unsigned long long sum = 0;
+    for (int i = t; i < n_tiles; i += kPlanThreads) { uint32_t c = cost_in[i]; if (c != 0xffffffffu) sum += c; }
+    sum = wave_sum(sum);
+    if ((t & 63) == 0) s_sum[t >> 6] = sum;
+    if (t < kCostBuckets) s_bucket[t] = 0;
+    __syncthreads();
+    if (t == 0) {
+        unsigned long long total = 0;
+        for (int w = 0; w < kPlanThreads / 64; w++) total += s_sum[w];
+        unsigned long long th = total / (unsigned long long)(slots > 0 ? slots : 1) / 16ull;
+        s_threshold = use_forced ? forced_threshold : (th > 0xfffffffeull ? 0xfffffffeu : (uint32_t)th);
+        s_heavy = 0;
+    }
+    __syncthreads();
+    const uint32_t threshold = s_threshold;
+    // heavy tiles by bucket of floor(log2(time)), longest first; within a bucket in order of arrival
+    for (int i = t; i < n_tiles; i += kPlanThreads) {
+        uint32_t c = cost_in[i];
+        if (c > threshold) atomicAdd(&s_bucket[31 - __clz(c | 1u)], 1u);
+    }
+    __syncthreads();
+    if (t == 0) {
+        uint32_t base = 0;
+        for (int b = kCostBuckets - 1; b >= 0; b--) { s_bucket_base[b] = base; base += s_bucket[b]; s_bucket[b] = 0; }
+        s_heavy = base;
+    }
+    __syncthreads();
+    const uint32_t n_heavy = s_heavy;
+    for (int i = t; i < n_tiles; i += kPlanThreads) {
+        uint32_t c = cost_in[i];
+        if (c > threshold) {
+            int b = 31 - __clz(c | 1u);
+            uint32_t pos = s_bucket_base[b] + atomicAdd(&s_bucket[b], 1u);
+            for (uint32_t quad = 0; quad < 4; quad++) items[4 * pos + quad] = (uint32_t)i | (quad << 28) | kItemQuadrant;
+        }
+    }
+    // light tiles after them, in frame order: every thread owns a run of consecutive tiles
+    const int run = (n_tiles + kPlanThreads - 1) / kPlanThreads;
+    const int lo = t * run, hi = lo + run < n_tiles ? lo + run : n_tiles;
+    uint32_t mine = 0;
+    for (int i = lo; i < hi; i++) mine += cost_in[i] > threshold ? 0u : 1u;
+    s_scan[t] = mine;
+    __syncthreads();
+    for (int off = 1; off < kPlanThreads; off <<= 1) {
+        uint32_t v = t >= off ? s_scan[t - off] : 0u;
+        __syncthreads();
+        s_scan[t] += v;
+        __syncthreads();
+    }
+    uint32_t at = 4 * n_heavy + s_scan[t] - mine;
+    for (int i = lo; i < hi; i++)
+        if (!(cost_in[i] > threshold)) items[at++] = (uint32_t)i;
+    for (int i = t; i < n_tiles; i += kPlanThreads) cost_out[i] = 0;
+    if (t == 0) { q->next = 0; q->n_items = 3 * n_heavy + (uint32_t)n_tiles; q->n_heavy = n_heavy; q->threshold = threshold; }
+}
+
+// (Every pointer the kernel writes through is a __restrict__ argument of its own: the scene tables are read in every
+// round of the item loop, after the stores of the rounds before, and only when the compiler knows that those stores
+// cannot touch the tables does it keep fetching them through the scalar cache.)
+struct QueueArgs { QueueHeader *q; const uint32_t *items; uint32_t *cost_out; };
+template <int F>
+__global__ __launch_bounds__(kBlock, split_waves(F, false)) void k_render_queue(DevScene S, RenderArgs a, float *__restrict__ rgb_tiles,
+                                                                                 uint8_t *__restrict__ rgb8_tiles,
+                                                                                 unsigned long long *__restrict__ counters,
+                                                                                 QueueHeader *__restrict__ q_hdr,
+                                                                                 const uint32_t *__restrict__ q_items,
+                                                                                 uint32_t *__restrict__ q_cost_out) {
+    QueueArgs qa = {q_hdr, q_items, q_cost_out};
+    unbundle(a);
+    RT_WAVE_STACK(stk, F);
+    __shared__ float tap_lds[kRoundTaps * 3 * 64];
+    __shared__ float s_grid_off[kMaxGrid];
+    __shared__ uint32_t s_item;
+    fill_grid_table(s_grid_off, a);
+    Work wk;
+    work_zero(wk);
+    const uint32_t n_items = (uint32_t)__builtin_amdgcn_readfirstlane((int32_t)qa.q->n_items);
+    for (;;) {
+        if (threadIdx.x == 0) s_item = atomicAdd(&qa.q->next, 1u);
+        __syncthreads();
+        const uint32_t at = (uint32_t)__builtin_amdgcn_readfirstlane((int32_t)s_item);  // block-uniform, and known to be so
+        __syncthreads();  // everybody has read s_item before thread 0 overwrites it in the next round
+        if (at >= n_items) break;
+        const uint32_t item = (uint32_t)__builtin_amdgcn_readfirstlane((int32_t)qa.items[at]);
+        const int local = (int)(item & 0x0fffffffu);
+        const unsigned long long t0 = wall_clock64();
+        render_item<F>(S, a, local, (item & kItemQuadrant) ? (int)((item >> 28) & 3u) : -1, stk, s_grid_off, tap_lds, rgb_tiles, rgb8_tiles, wk);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned long long dt = wall_clock64() - t0;
+            atomicAdd(&qa.cost_out[local], dt > 0x3fffffffull ? 0x3fffffffu : (uint32_t)dt);  // a heavy tile: the sum over its quadrants
+        }
+    }
+    flush_work(wk, counters, false);
 }
 
 // shards[r][local_tile][16][16][3] -> frame[y][x][3]; first_rank/n_ranks select which shards exist.
@@ -539,6 +751,18 @@ __global__ __launch_bounds__(kBlock) void k_intersect_object(DevScene S, int obj
 
 // ------------------------------------------------------------------ context
 
+// What k_render_hybrid and k_render_queue remember between frames: how long every tile took (read one array,
+// write the other), plus the queue's work list.
+struct TileMem {
+    QueueHeader *hdr = nullptr;
+    uint32_t *cost[2] = {nullptr, nullptr};
+    uint32_t *items = nullptr;  // nullptr: no room for the queue's list
+    int cap_tiles = 0;          // tiles the arrays hold
+    int turn = 0;               // cost[turn] holds the last frame's times
+    int32_t key[10] = {0};      // the frame parameters and scene those times belong to
+    bool valid = false;
+};
+
 struct rt_ctx {
     int device = 0;
     hipStream_t stream = nullptr;      // the stream in use
@@ -573,22 +797,10 @@ struct rt_ctx {
     bool split_forced = false;  // RT_SPLIT_MIN_TAPS (tests, tuning) sets the threshold for every scene
     int n_cus = 256;            // compute units of the device
     bool radix_tree = false;    // RT_BUILD=radix: the Morton radix tree instead of the surface-area splits
-    // Which of the render kernels (0: k_render, 1 and 2: k_render_split with one and two tap phases per wave; same
-    // pixels bit for bit) is fastest for the current frame parameters: each is timed once, on the first launches
-    // with these parameters.
-    struct Tune {
-        int32_t key[11] = {0};
-        bool valid = false;
-        hipEvent_t ev[kRenderVariants][2] = {};
-        bool recorded[kRenderVariants] = {}, have[kRenderVariants] = {};
-        float ms[kRenderVariants] = {};
-        int choice = -1;
-        int launches = 0;  // with this key
-    } tune;
     int split_phases = 1;  // RT_SPLIT_PHASES: which split kernel RT_SPLIT_MIN_TAPS selects
-    // k_render_hybrid: the time every tile took in the last frame, two arrays used in turn (read one, write the other)
-    uint32_t *d_tile_cost[2] = {nullptr, nullptr};
-    int tile_cost_cap = 0, tile_cost_turn = 0, hybrid_runs = 0;
+    TileMem tiles;              // tile times (and the queue's item list) of this context's launches
+    unsigned scene_serial = 0;  // counts scene uploads and updates: tile times of another scene are not used
+    int queue_slots[16] = {0};  // resident blocks of k_render_queue<features> on this device, by feature set (0: not asked yet)
     int forced_variant = -1;          // RT_RENDER_VARIANT: this kernel for every frame (tests)
     long long forced_threshold = -1;  // RT_HYBRID_THRESHOLD: ticks of 10 ns above which a tile counts as heavy (tests)
     int last_variant = 0;
@@ -644,13 +856,10 @@ extern "C" int rt_context_create(int device, rt_ctx **out) {
         return RT_ERR_HIP;
     }
     ctx->stream = ctx->own_stream;
-    for (int v = 0; v < kRenderVariants; v++)
-        for (int k = 0; k < 2; k++)
-            if (hipEventCreate(&ctx->tune.ev[v][k]) != hipSuccess) { delete ctx; return RT_ERR_HIP; }
     if (hipDeviceGetAttribute(&ctx->n_cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || ctx->n_cus <= 0) ctx->n_cus = 256;
     if (const char *e = std::getenv("RT_BUILD")) ctx->radix_tree = std::strcmp(e, "radix") == 0;
     if (const char *e = std::getenv("RT_SPLIT_PHASES")) ctx->split_phases = std::atoi(e) == 2 ? 2 : 1;
-    if (const char *e = std::getenv("RT_RENDER_VARIANT")) ctx->forced_variant = std::max(0, std::min(kRenderVariants - 1, std::atoi(e)));
+    if (const char *e = std::getenv("RT_RENDER_VARIANT")) ctx->forced_variant = std::max(0, std::min(kVariantQueue, std::atoi(e)));
     if (const char *e = std::getenv("RT_HYBRID_THRESHOLD")) ctx->forced_threshold = std::atoll(e);
     if (const char *e = std::getenv("RT_SPLIT_MIN_TAPS")) { ctx->split_min_taps = std::atoi(e); ctx->split_forced = true; }
     void *c = nullptr;
@@ -670,12 +879,9 @@ extern "C" int rt_context_destroy(rt_ctx *ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     free_scene(ctx);
     (void)hipFree(ctx->d_counters);
-    (void)hipFree(ctx->d_tile_cost[0]);
-    (void)hipFree(ctx->d_tile_cost[1]);
+    (void)hipFree(ctx->tiles.hdr);
     (void)hipEventDestroy(ctx->ev0);
     (void)hipEventDestroy(ctx->ev1);
-    for (int v = 0; v < kRenderVariants; v++)
-        for (int k = 0; k < 2; k++) (void)hipEventDestroy(ctx->tune.ev[v][k]);
     (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return RT_OK;
@@ -820,7 +1026,7 @@ extern "C" int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *sc) {
     RT_HIP(hipStreamSynchronize(ctx->stream));  // the caller's arrays may go away after return
     ctx->features = scene_features(sc);
     ctx->uploaded = true;
-    ctx->tune.valid = false;  // another scene: time the render kernels again
+    ctx->scene_serial++;
     ctx->built = false;
     ctx->n_textures = sc->n_textures;
     ctx->n_materials = sc->n_materials;
@@ -1028,6 +1234,7 @@ static int check_params(rt_ctx *ctx, const rt_render_params *p) {
     if (p->max_depth < 0 || p->max_depth > RT_MAX_DEPTH) return fail(ctx, RT_ERR_INVALID, "max_depth out of range");
     if (p->accel != RT_ACCEL_LBVH && p->accel != RT_ACCEL_BRUTE) return fail(ctx, RT_ERR_INVALID, "bad accel");
     if (p->world_size < 1 || p->rank < 0 || p->rank >= p->world_size) return fail(ctx, RT_ERR_INVALID, "bad rank/world_size");
+    if (p->kernel < RT_KERNEL_AUTO || p->kernel > RT_KERNEL_QUEUE) return fail(ctx, RT_ERR_INVALID, "bad kernel");
     if (!(p->fov > 0 && p->fov < 180)) return fail(ctx, RT_ERR_INVALID, "bad fov");
     return RT_OK;
 }
@@ -1048,12 +1255,47 @@ static int ready_for(rt_ctx *ctx, int accel) {
     return RT_OK;
 }
 
-extern "C" int rt_render_shard_device(rt_ctx *ctx, const rt_render_params *p, float *d_rgb_tiles, uint8_t *d_rgb8_tiles) {
-    if (!ctx) return RT_ERR_INVALID;
-    int rc = check_params(ctx, p);
-    if (rc) return rc;
-    if ((rc = ready_for(ctx, p->accel))) return rc;
-    RT_HIP(hipSetDevice(ctx->device));
+// Memory of the kernels that remember how long every tile took (k_render_hybrid, k_render_queue), for `tiles`
+// tiles in one piece: header, two time arrays used in turn and, for the queue, the item list (4 per tile at most).
+static size_t tile_mem_bytes(int tiles, bool with_items) { return sizeof(QueueHeader) + (size_t)tiles * (with_items ? 6 : 2) * sizeof(uint32_t); }
+static void tile_mem_carve(TileMem &tm, void *base, int tiles, bool with_items) {
+    unsigned char *b = static_cast<unsigned char *>(base);
+    tm.hdr = reinterpret_cast<QueueHeader *>(b);
+    tm.cost[0] = reinterpret_cast<uint32_t *>(b + sizeof(QueueHeader));
+    tm.cost[1] = tm.cost[0] + tiles;
+    tm.items = with_items ? tm.cost[1] + tiles : nullptr;
+    tm.cap_tiles = tiles;
+}
+
+template <int F>
+static int queue_slots_of(rt_ctx *ctx) {
+    int &slots = ctx->queue_slots[F];
+    if (slots == 0) {
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_render_queue<F>, kBlock, 0) != hipSuccess || per_cu <= 0) per_cu = 4;
+        slots = per_cu * ctx->n_cus;
+    }
+    return slots;
+}
+
+// Which kernel renders a launch.  The rule is fixed (no timing): a scene with meshes and at least four taps per
+// pixel goes to k_render_hybrid, whose per-tile choice between one block and four follows the tiles' times in the
+// previous frame -- measured on the 4K teapot frame it is within a few per cent of the best kernel for one GPU's
+// share of the frame at 1, 2, 4 and 8 GPUs, where k_render alone loses up to a factor 2.6 and the split kernels
+// up to 10 %; everything else goes to k_render.  rt_render_params.kernel or RT_RENDER_VARIANT name another one.
+static int pick_variant(const rt_ctx *ctx, const rt_render_params *p) {
+    if (p->count_work) return 0;  // the counting instantiation is k_render's
+    if (ctx->forced_variant >= 0) return ctx->forced_variant;
+    if (p->kernel > 0) return p->kernel - 1;
+    const int taps = taps_of(p->mode, p->grid_m);
+    if (ctx->split_forced) return taps >= ctx->split_min_taps ? ctx->split_phases : 0;
+    return ((ctx->features & F_MESH) && taps >= 4) ? 3 : 0;
+}
+
+// This rank's tiles of one frame into tile-major device buffers.  tm: where the tiles' times are kept (the
+// context's own memory, grown on demand when may_allocate, or the static array).
+static int render_shard(rt_ctx *ctx, const rt_render_params *p, float *d_rgb_tiles, uint8_t *d_rgb8_tiles, TileMem &tm, bool may_allocate,
+                        int variant) {
     RenderArgs a;
     a.width = p->width; a.height = p->height; a.mode = p->mode; a.grid_m = p->grid_m; a.max_depth = p->max_depth;
     a.accel = p->accel; a.rank = p->rank; a.world_size = p->world_size;
@@ -1061,137 +1303,100 @@ extern "C" int rt_render_shard_device(rt_ctx *ctx, const rt_render_params *p, fl
     int ty = (p->height + RT_TILE_H - 1) / RT_TILE_H;
     a.tiles_total = a.tiles_x * ty;
     a.cam = make_camera(p->width, p->height, p->fov);
-    int local_tiles = (a.tiles_total - p->rank + p->world_size - 1) / p->world_size;  // tiles t = b*W + rank < total
+    const int local_tiles = (a.tiles_total - p->rank + p->world_size - 1) / p->world_size;  // tiles t = b*W + rank < total
     if (local_tiles <= 0) return RT_OK;
-    RT_HIP(hipEventRecord(ctx->ev0, ctx->stream));
-    // the leanest instantiation that covers the scene's features; with many taps per pixel the
-    // variant that spreads a pixel's taps over the waves of a block
-    typedef void (*render_fn)(DevScene, RenderArgs, float *, uint8_t *, unsigned long long *);
-    // (meshes are what concentrates a frame's cost in few pixels; without them the split only adds its barriers)
-    // A block of k_render runs all taps of its pixels one after the other, and a tile on a mesh takes many times
-    // as long as the average tile.  With many taps, or with so few tiles per launch that the launch is no longer
-    // than a few such blocks (one rank's share of a frame on several GPUs), that one block decides the frame time
-    // and k_render_split, whose blocks are a quarter or an eighth as long, is faster in spite of its barriers.
-    // Which one wins depends on the scene, so each is timed once (first launches with these parameters; they
-    // write the same pixels) and the fastest is kept; until the timings are in, the rule of thumb below decides.
-    const int taps = taps_of(p->mode, p->grid_m);
-    const bool few_tiles = taps >= 2 * kRoundTaps && local_tiles < 16 * 5 * ctx->n_cus;  // under 16 rounds of resident blocks
-    int variant = 0;
-    const bool forced = ctx->split_forced || ctx->forced_variant >= 0;
-    if (ctx->forced_variant >= 0) variant = ctx->forced_variant;
-    else if (ctx->split_forced) variant = taps >= ctx->split_min_taps ? ctx->split_phases : 0;
-    else if ((ctx->features & F_MESH) && (taps >= ctx->split_min_taps || few_tiles)) variant = 1;
-    int measure = -1;
-    uint32_t threshold = ctx->forced_threshold >= 0 ? (uint32_t)std::min<long long>(ctx->forced_threshold, 0xffffffffll) : 20000u;
-    bool new_key = false;
-    if (!forced && !p->count_work && taps >= 4 && (ctx->features & F_MESH)) {
-        rt_ctx::Tune &t = ctx->tune;
+    const bool timed_tiles = variant == 3 || variant == kVariantQueue;
+    if (timed_tiles) {
+        if (local_tiles > tm.cap_tiles || (variant == kVariantQueue && !tm.items)) {
+            if (!may_allocate)
+                return fail(ctx, RT_ERR_LIMIT, "the launch has " + std::to_string(local_tiles) + " tiles; the entry point that allocates nothing holds " +
+                                                   std::to_string(tm.cap_tiles));
+            RT_HIP(hipStreamSynchronize(ctx->stream));
+            (void)hipFree(tm.hdr);
+            tm = TileMem();
+            void *mem = nullptr;
+            RT_HIP(hipMalloc(&mem, tile_mem_bytes(local_tiles, true)));
+            tile_mem_carve(tm, mem, local_tiles, true);
+        }
         int32_t fov_bits;
         std::memcpy(&fov_bits, &p->fov, sizeof fov_bits);
-        const int32_t key[11] = {p->width, p->height, p->mode, p->grid_m, p->max_depth, p->accel, p->rank, p->world_size,
-                                 fov_bits, ctx->features, 1};
-        if (!t.valid || std::memcmp(key, t.key, sizeof key) != 0) {
-            std::memcpy(t.key, key, sizeof key);
-            t.valid = true;
-            for (int v = 0; v < kRenderVariants; v++) t.recorded[v] = t.have[v] = false;
-            if (few_tiles) {  // k_render is known to lose here (a launch of few, very unequal blocks): not worth a frame
-                t.recorded[0] = t.have[0] = true;
-                t.ms[0] = INFINITY;
-            }
-            t.choice = -1;
-            t.launches = 0;
-            new_key = true;
+        const int32_t key[10] = {p->width, p->height, p->mode, p->grid_m, p->max_depth, p->rank, p->world_size, fov_bits, ctx->features,
+                                 (int32_t)ctx->scene_serial};
+        if (!tm.valid || std::memcmp(key, tm.key, sizeof key) != 0) {  // nothing known about these tiles: all count as heavy once
+            std::memcpy(tm.key, key, sizeof key);
+            tm.valid = true;
+            RT_HIP(hipMemsetAsync(tm.cost[tm.turn], 0xff, (size_t)local_tiles * sizeof(uint32_t), ctx->stream));
         }
-        for (int v = 0; v < kRenderVariants && t.choice < 0; v++)
-            if (t.recorded[v] && !t.have[v] && hipEventQuery(t.ev[v][1]) == hipSuccess &&
-                hipEventElapsedTime(&t.ms[v], t.ev[v][0], t.ev[v][1]) == hipSuccess)
-                t.have[v] = true;
-        (void)hipGetLastError();  // hipErrorNotReady from the query is not an error of this call
-        // k_render and the plain split kernel first.  Where splitting pays, the finer split is tried as well; where
-        // it pays or nearly does (the longest blocks matter), the per-tile choice, which learns the tiles' times in
-        // its first two launches, so that its third one is timed.  A tie goes to the simpler kernel.
-        const bool both = t.have[0] && t.have[1];
-        const bool pays = both && t.ms[1] < 0.98f * t.ms[0], near = both && t.ms[1] < 1.1f * t.ms[0];
-        if (t.choice < 0 && both && (!pays || t.have[2]) && (!near || t.have[3])) {
-            t.choice = 0;
-            for (int v = 1; v < kRenderVariants; v++)
-                if (t.have[v] && t.ms[v] < 0.98f * t.ms[t.choice]) t.choice = v;
-        }
-        if (both)  // a tile is heavy when it takes 1.5 times the average tile's share of a launch
-            threshold = (uint32_t)std::min(4.0e9, 1.5 * std::min(t.ms[0], t.ms[1]) * 5.0 * ctx->n_cus / local_tiles * 1.0e5);
-        if (t.choice >= 0) variant = t.choice;
-        // The first launch runs cold (clocks, caches: 15 % slower) and is not one to time.  Where the rule of thumb is
-        // on firm ground (many tiles) trying the other kernels costs more than a short sequence can win back: there
-        // the timing starts with the 16th frame.
-        else if (t.launches < (few_tiles ? 1 : 16)) {}
-        else if (!t.recorded[0]) variant = measure = 0;
-        else if (!t.recorded[1]) variant = measure = 1;
-        else if (pays && !t.recorded[2]) variant = measure = 2;
-        else if (near && ctx->hybrid_runs < 2) variant = 3;  // all tiles split, then a first sorting: the third launch is the typical one
-        else if (near && !t.recorded[3]) variant = measure = 3;
-        else if (pays) variant = 1;  // waiting for the last timings
-        t.launches++;
     }
-    if (ctx->forced_threshold >= 0) threshold = (uint32_t)std::min<long long>(ctx->forced_threshold, 0xffffffffll);
-    if (p->count_work) variant = 0;  // (the counting instantiation exists for k_render and the split kernels; any gives the same counts)
+    RT_HIP(hipEventRecord(ctx->ev0, ctx->stream));
     ctx->last_variant = variant;
-    int f = ctx->features;
-    render_fn kernel;
-#define RT_PICK(FEATURES, COUNT)                                                              \
-    (variant == 0 ? (render_fn)k_render<FEATURES, COUNT>                                      \
-                  : variant == 1 ? (render_fn)k_render_split<FEATURES, COUNT, 1> : (render_fn)k_render_split<FEATURES, COUNT, 2>)
-    if (p->count_work) kernel = (render_fn)k_render<F_ALL, true>;
-    else if (f == 0) kernel = RT_PICK(0, false);
-    else if ((f & ~F_MESH) == 0) kernel = RT_PICK(F_MESH, false);
-    else if ((f & ~(F_MESH | F_SECONDARY)) == 0) kernel = RT_PICK(F_MESH | F_SECONDARY, false);
-    else if ((f & ~(F_QUADRIC | F_SECONDARY)) == 0) kernel = RT_PICK(F_QUADRIC | F_SECONDARY, false);
-    else if ((f & ~(F_QUADRIC | F_TEXTURE | F_SECONDARY)) == 0) kernel = RT_PICK(F_QUADRIC | F_TEXTURE | F_SECONDARY, false);
-    else if ((f & ~(F_MESH | F_TEXTURE | F_SECONDARY)) == 0) kernel = RT_PICK(F_MESH | F_TEXTURE | F_SECONDARY, false);
-    else kernel = RT_PICK(F_ALL, false);
-#undef RT_PICK
-    const int blocks_per_tile = variant == 0 ? 1 : variant == 2 ? 8 : 4;
-    TileCosts tc = {nullptr, nullptr, threshold};
-    if (variant == 3) {
-        if (local_tiles > ctx->tile_cost_cap) {
-            ctx->tile_cost_cap = 0;  // (stays 0 if an allocation below fails)
-            RT_HIP(hipStreamSynchronize(ctx->stream));
-            for (int k = 0; k < 2; k++) {
-                (void)hipFree(ctx->d_tile_cost[k]);
-                ctx->d_tile_cost[k] = nullptr;
-                RT_HIP(hipMalloc((void **)&ctx->d_tile_cost[k], (size_t)local_tiles * sizeof(uint32_t)));
-            }
-            ctx->tile_cost_cap = local_tiles;
-            new_key = true;
-        }
-        if (new_key || ctx->hybrid_runs == 0)  // nothing known about these tiles: all heavy in the first launch (the safe side for a short launch)
-            RT_HIP(hipMemsetAsync(ctx->d_tile_cost[ctx->tile_cost_turn], 0xff, (size_t)local_tiles * sizeof(uint32_t), ctx->stream));
-        tc.cost_in = ctx->d_tile_cost[ctx->tile_cost_turn];
-        tc.cost_out = ctx->d_tile_cost[ctx->tile_cost_turn ^ 1];
-        ctx->tile_cost_turn ^= 1;
-        ctx->hybrid_runs++;
-    }
-    if (new_key && variant != 3) ctx->hybrid_runs = 0;
-    if (measure >= 0) RT_HIP(hipEventRecord(ctx->tune.ev[measure][0], ctx->stream));
-    if (variant == 3) {
+    const int f = ctx->features;
+    const uint32_t forced_threshold = ctx->forced_threshold >= 0 ? (uint32_t)std::min<long long>(ctx->forced_threshold, 0xfffffffell) : 0u;
+    const int use_forced = ctx->forced_threshold >= 0 ? 1 : 0;
+    if (variant == kVariantQueue) {
+        typedef void (*queue_fn)(DevScene, RenderArgs, float *, uint8_t *, unsigned long long *, QueueHeader *, const uint32_t *, uint32_t *);
+        queue_fn kernel;
+        int slots;
+#define RT_QUEUE(FEATURES) (kernel = k_render_queue<FEATURES>, slots = queue_slots_of<FEATURES>(ctx))
+        if (f == 0) RT_QUEUE(0);
+        else if ((f & ~F_MESH) == 0) RT_QUEUE(F_MESH);
+        else if ((f & ~(F_MESH | F_SECONDARY)) == 0) RT_QUEUE(F_MESH | F_SECONDARY);
+        else if ((f & ~(F_QUADRIC | F_SECONDARY)) == 0) RT_QUEUE(F_QUADRIC | F_SECONDARY);
+        else if ((f & ~(F_QUADRIC | F_TEXTURE | F_SECONDARY)) == 0) RT_QUEUE(F_QUADRIC | F_TEXTURE | F_SECONDARY);
+        else if ((f & ~(F_MESH | F_TEXTURE | F_SECONDARY)) == 0) RT_QUEUE(F_MESH | F_TEXTURE | F_SECONDARY);
+        else RT_QUEUE(F_ALL);
+#undef RT_QUEUE
+        const int blocks = std::min(slots, 4 * local_tiles);
+        hipLaunchKernelGGL(k_plan_tiles, dim3(1), dim3(kPlanThreads), 0, ctx->stream, tm.hdr, tm.cost[tm.turn], tm.cost[tm.turn ^ 1], tm.items,
+                           local_tiles, blocks, forced_threshold, use_forced);
+        hipLaunchKernelGGL(kernel, dim3(blocks), dim3(kBlock), 0, ctx->stream, ctx->S, a, d_rgb_tiles, d_rgb8_tiles, ctx->d_counters, tm.hdr,
+                           (const uint32_t *)tm.items, tm.cost[tm.turn ^ 1]);
+        tm.turn ^= 1;
+    } else if (variant == 3) {
         typedef void (*hybrid_fn)(DevScene, RenderArgs, float *, uint8_t *, unsigned long long *, TileCosts);
         hybrid_fn hk = k_render_hybrid<F_ALL>;
         if ((f & ~F_MESH) == 0) hk = k_render_hybrid<F_MESH>;
         else if ((f & ~(F_MESH | F_SECONDARY)) == 0) hk = k_render_hybrid<F_MESH | F_SECONDARY>;
         else if ((f & ~(F_MESH | F_TEXTURE | F_SECONDARY)) == 0) hk = k_render_hybrid<F_MESH | F_TEXTURE | F_SECONDARY>;
-        hipLaunchKernelGGL(hk, dim3(4 * local_tiles), dim3(kBlock), 0, ctx->stream, ctx->S, a, d_rgb_tiles, d_rgb8_tiles,
-                           ctx->d_counters, tc);
+        // a tile is heavy when it took more than 1.5 times the average tile: the threshold is formed on the device
+        // from last frame's times, so that no frame waits for the host to look at them
+        hipLaunchKernelGGL(k_tile_threshold, dim3(1), dim3(kPlanThreads), 0, ctx->stream, tm.hdr, (const uint32_t *)tm.cost[tm.turn], local_tiles,
+                           forced_threshold, use_forced);
+        TileCosts tc = {tm.cost[tm.turn], tm.cost[tm.turn ^ 1], &tm.hdr->threshold};
+        hipLaunchKernelGGL(hk, dim3(4 * local_tiles), dim3(kBlock), 0, ctx->stream, ctx->S, a, d_rgb_tiles, d_rgb8_tiles, ctx->d_counters, tc);
+        tm.turn ^= 1;
     } else {
-        hipLaunchKernelGGL(kernel, dim3(blocks_per_tile * local_tiles), dim3(kBlock), 0, ctx->stream, ctx->S, a, d_rgb_tiles,
-                           d_rgb8_tiles, ctx->d_counters);
+        typedef void (*render_fn)(DevScene, RenderArgs, float *, uint8_t *, unsigned long long *);
+        render_fn kernel;
+#define RT_PICK(FEATURES, COUNT)                                                              \
+    (variant == 0 ? (render_fn)k_render<FEATURES, COUNT>                                      \
+                  : variant == 1 ? (render_fn)k_render_split<FEATURES, COUNT, 1> : (render_fn)k_render_split<FEATURES, COUNT, 2>)
+        if (p->count_work) kernel = (render_fn)k_render<F_ALL, true>;
+        else if (f == 0) kernel = RT_PICK(0, false);
+        else if ((f & ~F_MESH) == 0) kernel = RT_PICK(F_MESH, false);
+        else if ((f & ~(F_MESH | F_SECONDARY)) == 0) kernel = RT_PICK(F_MESH | F_SECONDARY, false);
+        else if ((f & ~(F_QUADRIC | F_SECONDARY)) == 0) kernel = RT_PICK(F_QUADRIC | F_SECONDARY, false);
+        else if ((f & ~(F_QUADRIC | F_TEXTURE | F_SECONDARY)) == 0) kernel = RT_PICK(F_QUADRIC | F_TEXTURE | F_SECONDARY, false);
+        else if ((f & ~(F_MESH | F_TEXTURE | F_SECONDARY)) == 0) kernel = RT_PICK(F_MESH | F_TEXTURE | F_SECONDARY, false);
+        else kernel = RT_PICK(F_ALL, false);
+#undef RT_PICK
+        const int blocks_per_tile = variant == 0 ? 1 : variant == 2 ? 8 : 4;
+        hipLaunchKernelGGL(kernel, dim3(blocks_per_tile * local_tiles), dim3(kBlock), 0, ctx->stream, ctx->S, a, d_rgb_tiles, d_rgb8_tiles,
+                           ctx->d_counters);
     }
     RT_HIP(hipGetLastError());
-    if (measure >= 0) {
-        RT_HIP(hipEventRecord(ctx->tune.ev[measure][1], ctx->stream));
-        ctx->tune.recorded[measure] = true;
-    }
     RT_HIP(hipEventRecord(ctx->ev1, ctx->stream));
     ctx->trace_timed = true;
     return RT_OK;
+}
+
+extern "C" int rt_render_shard_device(rt_ctx *ctx, const rt_render_params *p, float *d_rgb_tiles, uint8_t *d_rgb8_tiles) {
+    if (!ctx) return RT_ERR_INVALID;
+    int rc = check_params(ctx, p);
+    if (rc) return rc;
+    if ((rc = ready_for(ctx, p->accel))) return rc;
+    RT_HIP(hipSetDevice(ctx->device));
+    return render_shard(ctx, p, d_rgb_tiles, d_rgb8_tiles, ctx->tiles, true, pick_variant(ctx, p));
 }
 
 static int untile_on(rt_ctx *ctx, hipStream_t stream, const rt_render_params *p, const float *d_rgb_shards, float *d_rgb_frame,

@@ -424,23 +424,28 @@ def test_tall_tree_equals_brute_force_on_gpu(builder, monkeypatch):
     parity.check_radiance(rc, ra, "tall tree")
 
 
-def test_render_kernel_choice_by_timing_keeps_the_pixels(gpu_ctx):
-    """With new frame parameters the first seventeen launches run the one-lane-per-pixel kernel (the last one timed), the next the kernel that
-    spreads a pixel's taps over a block's waves; if that paid, the finer split and the per-tile choice (twice: it
-    learns in its first launches) follow, and then the fastest is kept: 26 frames, up to four kernels, the
-    same bytes."""
-    if os.environ.get("RT_SPLIT_MIN_TAPS"):
-        pytest.skip("the environment fixes the kernel choice")
+def test_every_render_kernel_writes_the_same_pixels(gpu_ctx):
+    """The render kernels differ in who renders a pixel and when, never in its value: each kernel named through
+    rt_render_params.kernel, over several frames (the per-tile and the queue kernel plan a frame from the tiles'
+    times in the frame before), gives the bytes of the one-lane-per-pixel kernel.  The automatic choice is a fixed
+    rule: the same kernel for every frame of a sequence."""
     ctx = gpu_ctx("teapot")
-    frames, variants = [], []
-    for _ in range(26):
-        frames.append(ctx.render(333, 177, fov=77.0, mode=rt.MODE_GRID, grid_m=3))
-        variants.append(ctx.counters().render_variant)
-    assert variants[:18] == [0] * 17 + [1]  # (no timing before the 16th frame of a sequence; then k_render, then the split)
-    assert variants[18:22] in ([2, 3, 3, 3], [3, 3, 3, variants[21]], [0, 0, 0, 0]), variants
-    assert len(set(variants[22:])) == 1
-    for rgb, rgb8 in frames[1:]:
-        assert np.array_equal(rgb8, frames[0][1]) and np.array_equal(rgb, frames[0][0], equal_nan=True)
+    kw = dict(fov=77.0, mode=rt.MODE_GRID, grid_m=3)
+    ref, ref8 = ctx.render(333, 177, kernel=rt.KERNEL_PIXEL, **kw)
+    assert ctx.counters().render_variant == rt.KERNEL_PIXEL - 1
+    for kernel in (rt.KERNEL_SPLIT, rt.KERNEL_SPLIT2, rt.KERNEL_PER_TILE, rt.KERNEL_QUEUE, rt.KERNEL_AUTO):
+        variants = []
+        for _ in range(4):
+            rgb, rgb8 = ctx.render(333, 177, kernel=kernel, **kw)
+            variants.append(ctx.counters().render_variant)
+            assert np.array_equal(rgb8, ref8) and np.array_equal(rgb, ref, equal_nan=True), (kernel, variants)
+        expect = kernel - 1 if kernel != rt.KERNEL_AUTO else rt.KERNEL_PER_TILE - 1  # a mesh scene with nine taps
+        assert variants == [expect] * 4
+    # scenes without meshes, and single-tap frames, go to the one-lane-per-pixel kernel
+    ctx.render(96, 64, mode=rt.MODE_REF_1SPP)
+    assert ctx.counters().render_variant == rt.KERNEL_PIXEL - 1
+    gpu_ctx("analytic").render(96, 64, mode=rt.MODE_REF_AA9)
+    assert gpu_ctx("analytic").counters().render_variant == rt.KERNEL_PIXEL - 1
 
 
 @pytest.mark.parametrize("seed", range(8))
