@@ -127,7 +127,8 @@ HIT_DTYPE = np.dtype([("hit", "i4"), ("object", "i4"), ("frag", "i4"), ("sub", "
 ABI_SYMBOLS = ["rt_context_create", "rt_context_destroy", "rt_last_error", "rt_scene_upload", "rt_scene_update",
                "rt_build_accel", "rt_render", "rt_shard_tiles", "rt_render_shard_device",
                "rt_untile_device", "rt_sync", "rt_stream", "rt_set_stream", "rt_trace_rays", "rt_intersect_object",
-               "rt_get_counters", "rt_reset_counters", "rt_debug_copy_bvh", "rt_untile_device_on"]
+               "rt_get_counters", "rt_reset_counters", "rt_debug_copy_bvh", "rt_untile_device_on",
+               "rt_render_shard_device_noalloc"]
 
 _amd = None
 _host = None
@@ -159,6 +160,7 @@ def amd():
         L.rt_render.argtypes = [vp, C.POINTER(RenderParams), vp, vp]
         L.rt_shard_tiles.argtypes = [C.POINTER(RenderParams), C.POINTER(i32), C.POINTER(i32)]
         L.rt_render_shard_device.argtypes = [vp, C.POINTER(RenderParams), vp, vp]
+        L.rt_render_shard_device_noalloc.argtypes = [vp, C.POINTER(RenderParams), vp, vp]
         L.rt_untile_device.argtypes = [vp, C.POINTER(RenderParams), vp, vp, vp, vp]
         L.rt_untile_device_on.argtypes = [vp, vp, C.POINTER(RenderParams), vp, vp, vp, vp]
         L.rt_sync.argtypes = [vp]
@@ -425,6 +427,10 @@ class Context:
     def render_shard_device(self, p, d_rgb_tiles, d_rgb8_tiles):
         self._check(self.L.rt_render_shard_device(self.h, C.byref(p), d_rgb_tiles, d_rgb8_tiles),
                     "rt_render_shard_device")
+
+    def render_shard_device_noalloc(self, p, d_rgb_tiles, d_rgb8_tiles):
+        self._check(self.L.rt_render_shard_device_noalloc(self.h, C.byref(p), d_rgb_tiles, d_rgb8_tiles),
+                    "rt_render_shard_device_noalloc")
 
     def untile_device(self, p, d_rgb_shards, d_rgb_frame, d_rgb8_shards, d_rgb8_frame):
         self._check(self.L.rt_untile_device(self.h, C.byref(p), d_rgb_shards, d_rgb_frame,

@@ -842,6 +842,8 @@ static void free_scene(rt_ctx *ctx) {
     ctx->S = DevScene{};
 }
 
+static int noalloc_setup(rt_ctx *ctx);  // (below, next to the static tile memory)
+
 extern "C" int rt_context_create(int device, rt_ctx **out) {
     if (!out) return RT_ERR_INVALID;
     *out = nullptr;
@@ -869,6 +871,11 @@ extern "C" int rt_context_create(int device, rt_ctx **out) {
         return RT_ERR_HIP;
     }
     ctx->d_counters = static_cast<unsigned long long *>(c);
+    if (noalloc_setup(ctx) != RT_OK) {  // the address of this device's copy of the static tile memory
+        (void)hipFree(c);
+        delete ctx;
+        return RT_ERR_HIP;
+    }
     *out = ctx;
     return RT_OK;
 }
@@ -1267,6 +1274,28 @@ static void tile_mem_carve(TileMem &tm, void *base, int tiles, bool with_items) 
     tm.cap_tiles = tiles;
 }
 
+// ---- the entry point that allocates nothing: its tile times live in a file-scope device array
+//
+// One array per GPU (every device that loads this library holds its own copy, at its own address, until the
+// process ends).  Host code never uses the array's name as an address: rt_context_create asks the runtime
+// for the address on the context's device (hipGetSymbolAddress) and everything below works with that pointer.
+constexpr int kNoAllocMaxTiles = 65536;  // e.g. a 4096 x 4096 frame on one GPU, or 8192 x 8192 split over four
+constexpr size_t kNoAllocBytes = sizeof(QueueHeader) + (size_t)kNoAllocMaxTiles * 2 * sizeof(uint32_t);
+static __device__ __align__(256) unsigned char scratch[kNoAllocBytes];
+constexpr int kMaxDevices = 64;
+static TileMem g_noalloc[kMaxDevices];  // per device: the carved pointer into that device's array and what its times belong to
+static bool g_noalloc_ready[kMaxDevices];
+
+static int noalloc_setup(rt_ctx *ctx) {  // once per device, with that device current
+    if (ctx->device < 0 || ctx->device >= kMaxDevices) return RT_OK;  // (such a device gets RT_ERR_LIMIT from the entry point)
+    if (g_noalloc_ready[ctx->device]) return RT_OK;
+    void *ptr = nullptr;
+    RT_HIP(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+    tile_mem_carve(g_noalloc[ctx->device], ptr, kNoAllocMaxTiles, false);
+    g_noalloc_ready[ctx->device] = true;
+    return RT_OK;
+}
+
 template <int F>
 static int queue_slots_of(rt_ctx *ctx) {
     int &slots = ctx->queue_slots[F];
@@ -1397,6 +1426,19 @@ extern "C" int rt_render_shard_device(rt_ctx *ctx, const rt_render_params *p, fl
     if ((rc = ready_for(ctx, p->accel))) return rc;
     RT_HIP(hipSetDevice(ctx->device));
     return render_shard(ctx, p, d_rgb_tiles, d_rgb8_tiles, ctx->tiles, true, pick_variant(ctx, p));
+}
+
+extern "C" int rt_render_shard_device_noalloc(rt_ctx *ctx, const rt_render_params *p, float *d_rgb_tiles, uint8_t *d_rgb8_tiles) {
+    if (!ctx) return RT_ERR_INVALID;
+    int rc = check_params(ctx, p);
+    if (rc) return rc;
+    if ((rc = ready_for(ctx, p->accel))) return rc;
+    if (p->count_work) return fail(ctx, RT_ERR_INVALID, "rt_render_shard_device_noalloc does not count work");
+    if (ctx->device < 0 || ctx->device >= kMaxDevices || !g_noalloc_ready[ctx->device])
+        return fail(ctx, RT_ERR_LIMIT, "no static tile memory for device " + std::to_string(ctx->device));
+    RT_HIP(hipSetDevice(ctx->device));
+    // always the kernel that keeps tile times (they are what lives in the static array)
+    return render_shard(ctx, p, d_rgb_tiles, d_rgb8_tiles, g_noalloc[ctx->device], false, 3);
 }
 
 static int untile_on(rt_ctx *ctx, hipStream_t stream, const rt_render_params *p, const float *d_rgb_shards, float *d_rgb_frame,
