@@ -286,6 +286,12 @@ __global__ void k_octant_variants(BvhNode *nodes, int n) {
     int o = 1 + idx / n, i = idx % n;
     nodes[(size_t)o * n + i] = lbvh_octant_variant(nodes[i], o);
 }
+// then the fitted tree itself becomes the variant of octant 0 (its children put in that octant's order), in place
+__global__ void k_octant_variant0(BvhNode *nodes, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    nodes[i] = lbvh_octant_variant(nodes[i], 0);
+}
 
 // One 16x16 tile by one block: each wave an 8x8 quadrant, each lane a pixel with all its taps.
 template <int F, bool COUNT>
@@ -1206,6 +1212,7 @@ extern "C" int rt_build_accel(rt_ctx *ctx) {
                                ctx->d_nodes + m.node_offset, root, d_root + i);
             int nv = (n - 1) * (kOctants - 1);
             hipLaunchKernelGGL(k_octant_variants, dim3((nv + 255) / 256), blk, 0, ctx->stream, ctx->d_nodes + m.node_offset, n - 1);
+            hipLaunchKernelGGL(k_octant_variant0, dim3((n - 1 + 255) / 256), blk, 0, ctx->stream, ctx->d_nodes + m.node_offset, n - 1);
         }
     }
     (void)hipEventRecord(ctx->ev1, ctx->stream);

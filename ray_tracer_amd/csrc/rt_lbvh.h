@@ -171,15 +171,27 @@ RT_HD int lbvh_fit_node(int i, int pass, const int32_t *c0s, const int32_t *c1s,
 }
 
 // The variant of a plain node for ray-direction octant o: near faces in the lo slots, far faces in
-// the hi slots (bit a of o set: direction component a negative, so the near face is the hi bound).
+// the hi slots (bit a of o set: direction component a negative, so the near face is the hi bound),
+// and the child that lies in front along the octant's diagonal (by the projection of the box centres; a tie or
+// a centre that is not a number keeps the order) in slot 0: the walk visits slot 0 first without comparing.
 RT_HD BvhNode lbvh_octant_variant(const BvhNode &n, int o) {
+    float k0 = 0, k1 = 0;
+    for (int a = 0; a < 3; a++) {
+        float c0 = n.lo0[a] + n.hi0[a], c1 = n.lo1[a] + n.hi1[a];
+        k0 += ((o >> a) & 1) ? -c0 : c0;
+        k1 += ((o >> a) & 1) ? -c1 : c1;
+    }
+    const bool swap = k1 < k0;
     BvhNode v = n;
     for (int a = 0; a < 3; a++) {
-        if ((o >> a) & 1) {
-            v.lo0[a] = n.hi0[a]; v.hi0[a] = n.lo0[a];
-            v.lo1[a] = n.hi1[a]; v.hi1[a] = n.lo1[a];
-        }
+        const bool neg = ((o >> a) & 1) != 0;
+        const float lo0 = neg ? n.hi0[a] : n.lo0[a], hi0 = neg ? n.lo0[a] : n.hi0[a];
+        const float lo1 = neg ? n.hi1[a] : n.lo1[a], hi1 = neg ? n.lo1[a] : n.hi1[a];
+        v.lo0[a] = swap ? lo1 : lo0; v.hi0[a] = swap ? hi1 : hi0;
+        v.lo1[a] = swap ? lo0 : lo1; v.hi1[a] = swap ? hi0 : hi1;
     }
+    v.c0 = swap ? n.c1 : n.c0;
+    v.c1 = swap ? n.c0 : n.c1;
     return v;
 }
 

@@ -237,6 +237,7 @@ int twin_build_accel(void *h) {
         for (int o = 1; o < kOctants; o++)
             for (int i = 0; i < n - 1; i++)
                 t->nodes[m.node_offset + (size_t)o * (n - 1) + i] = lbvh_octant_variant(t->nodes[m.node_offset + i], o);
+        for (int i = 0; i < n - 1; i++) t->nodes[m.node_offset + i] = lbvh_octant_variant(t->nodes[m.node_offset + i], 0);
         t->build[mi].height = height[root];
         t->bvh_max_depth = std::max(t->bvh_max_depth, height[root]);
     }
