@@ -1314,18 +1314,22 @@ static int queue_slots_of(rt_ctx *ctx) {
     return slots;
 }
 
-// Which kernel renders a launch.  The rule is fixed (no timing): a scene with meshes and at least four taps per
-// pixel goes to k_render_hybrid, whose per-tile choice between one block and four follows the tiles' times in the
-// previous frame -- measured on the 4K teapot frame it is within a few per cent of the best kernel for one GPU's
-// share of the frame at 1, 2, 4 and 8 GPUs, where k_render alone loses up to a factor 2.6 and the split kernels
-// up to 10 %; everything else goes to k_render.  rt_render_params.kernel or RT_RENDER_VARIANT name another one.
-static int pick_variant(const rt_ctx *ctx, const rt_render_params *p) {
+// Which kernel renders a launch.  The rule is fixed (no timing).  A block of k_render walks all taps of its pixels
+// one after the other, and a tile on a mesh takes many times as long as the average tile: with many taps per pixel,
+// or with so few tiles that the launch is only a few such blocks long (one GPU's share of a frame on a node of
+// several), the longest blocks decide the time.  There k_render_hybrid renders the tiles that took long in the
+// previous frame with four blocks each (measured on one GPU's share of the 4K teapot frame at 2 / 4 / 8 GPUs:
+// 1.48 / 0.77 / 0.46 ms against k_render's 2.06 / 1.48 / 1.23).  Everything else goes to k_render, which has the
+// fewest instructions per ray.  rt_render_params.kernel or RT_RENDER_VARIANT name another kernel.
+static int pick_variant(const rt_ctx *ctx, const rt_render_params *p, int local_tiles) {
     if (p->count_work) return 0;  // the counting instantiation is k_render's
     if (ctx->forced_variant >= 0) return ctx->forced_variant;
     if (p->kernel > 0) return p->kernel - 1;
     const int taps = taps_of(p->mode, p->grid_m);
     if (ctx->split_forced) return taps >= ctx->split_min_taps ? ctx->split_phases : 0;
-    return ((ctx->features & F_MESH) && taps >= 4) ? 3 : 0;
+    if (!(ctx->features & F_MESH) || taps < 4) return 0;
+    const bool short_launch = local_tiles < 16 * 5 * ctx->n_cus;  // under 16 rounds of resident blocks
+    return (taps >= 32 || short_launch) ? 3 : 0;
 }
 
 // This rank's tiles of one frame into tile-major device buffers.  tm: where the tiles' times are kept (the
@@ -1432,7 +1436,9 @@ extern "C" int rt_render_shard_device(rt_ctx *ctx, const rt_render_params *p, fl
     if (rc) return rc;
     if ((rc = ready_for(ctx, p->accel))) return rc;
     RT_HIP(hipSetDevice(ctx->device));
-    return render_shard(ctx, p, d_rgb_tiles, d_rgb8_tiles, ctx->tiles, true, pick_variant(ctx, p));
+    int per_rank = 0, total = 0;
+    rt_shard_tiles(p, &per_rank, &total);
+    return render_shard(ctx, p, d_rgb_tiles, d_rgb8_tiles, ctx->tiles, true, pick_variant(ctx, p, per_rank));
 }
 
 extern "C" int rt_render_shard_device_noalloc(rt_ctx *ctx, const rt_render_params *p, float *d_rgb_tiles, uint8_t *d_rgb8_tiles) {
