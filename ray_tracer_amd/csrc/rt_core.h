@@ -1064,8 +1064,7 @@ RT_HD v3 refract_dir(v3 i, v3 n, float index) {
 
 // What PhongModel (main.cpp:642-695) needs while the shadow rays of one hit are in flight.
 struct ShadeCtx {
-    v3 point, normal, d_in;  // d_in: direction of the ray that produced the hit
-    v3 view;                 // normalize(-d_in)
+    v3 point, normal, d_in;  // d_in: direction of the ray that produced the hit (the view vector is normalize(-d_in))
     v3 color;                // running sum, starts at ambient_light * material.ambient
     v3 dc;                   // diffuse colour (texture(uv) or material.diffuse), x5 for image textures
     uint32_t occlusion_px;   // RGBA8 texel of the occlusion map (image-textured surfaces)
@@ -1078,39 +1077,38 @@ struct ShadeCtx {
 // the Stack policy (LDS columns on the GPU: cold_put(slot, float) / cold_get(slot)), so that it holds no
 // registers during the traversal; without this the 96-register build of the render kernel spilled to
 // scratch memory.
-constexpr int kColdSlots = 26;  // 22 without secondary rays: see cold_slots()
+constexpr int kColdSlots = 23;  // 22 without secondary rays: see cold_slots()
 RT_HD float i2f(int32_t i) { return u2f((uint32_t)i); }
 template <class Stack>
 RT_HD void cold_put3(Stack &stk, int slot, v3 v) { stk.cold_put(slot, v.x); stk.cold_put(slot + 1, v.y); stk.cold_put(slot + 2, v.z); }
 template <class Stack>
 RT_HD v3 cold_get3(Stack &stk, int slot) { return V3(stk.cold_get(slot), stk.cold_get(slot + 1), stk.cold_get(slot + 2)); }
-enum : int { kColdPoint = 0, kColdNormal = 3, kColdView = 6, kColdColor = 9, kColdDc = 12, kColdOcclusion = 15, kColdShininess = 16,
-             kColdMaterial = 17, kColdL = 18, kColdLightR = 21, kColdDirIn = 22, kColdOutside = 25 };
-// d_in and from_outside only matter for reflection / refraction: the last four slots
-constexpr int cold_slots(int features) { return (features & F_SECONDARY) ? kColdSlots : kColdDirIn; }
+enum : int { kColdPoint = 0, kColdNormal = 3, kColdDirIn = 6, kColdColor = 9, kColdDc = 12, kColdOcclusion = 15, kColdShininess = 16,
+             kColdMaterial = 17, kColdL = 18, kColdLightR = 21, kColdOutside = 22 };
+// from_outside only matters for reflection / refraction: the last slot
+constexpr int cold_slots(int features) { return (features & F_SECONDARY) ? kColdSlots : kColdOutside; }
 template <int F, class Stack>
 RT_HD void park_shade(Stack &stk, const ShadeCtx &sc) {
     cold_put3(stk, kColdPoint, sc.point); cold_put3(stk, kColdNormal, sc.normal);
-    cold_put3(stk, kColdView, sc.view); cold_put3(stk, kColdColor, sc.color); cold_put3(stk, kColdDc, sc.dc);
+    cold_put3(stk, kColdDirIn, sc.d_in); cold_put3(stk, kColdColor, sc.color); cold_put3(stk, kColdDc, sc.dc);
     stk.cold_put(kColdOcclusion, u2f(sc.occlusion_px)); stk.cold_put(kColdShininess, sc.shininess);
     stk.cold_put(kColdMaterial, i2f(sc.material));
-    if (F & F_SECONDARY) { cold_put3(stk, kColdDirIn, sc.d_in); stk.cold_put(kColdOutside, sc.from_outside ? 1.0f : 0.0f); }
+    if (F & F_SECONDARY) stk.cold_put(kColdOutside, sc.from_outside ? 1.0f : 0.0f);
 }
 template <int F, class Stack>
 RT_HD void unpark_shade(Stack &stk, ShadeCtx &sc) {
     sc.point = cold_get3(stk, kColdPoint); sc.normal = cold_get3(stk, kColdNormal);
-    sc.view = cold_get3(stk, kColdView); sc.color = cold_get3(stk, kColdColor); sc.dc = cold_get3(stk, kColdDc);
+    sc.d_in = cold_get3(stk, kColdDirIn); sc.color = cold_get3(stk, kColdColor); sc.dc = cold_get3(stk, kColdDc);
     sc.occlusion_px = (uint32_t)f2i(stk.cold_get(kColdOcclusion)); sc.shininess = stk.cold_get(kColdShininess);
     sc.material = f2i(stk.cold_get(kColdMaterial));
-    sc.d_in = V3(0, 0, 0); sc.from_outside = true;
-    if (F & F_SECONDARY) { sc.d_in = cold_get3(stk, kColdDirIn); sc.from_outside = stk.cold_get(kColdOutside) != 0.0f; }
+    sc.from_outside = true;
+    if (F & F_SECONDARY) sc.from_outside = stk.cold_get(kColdOutside) != 0.0f;
 }
 
 template <int F, bool COUNT>
 RT_HD void shade_begin(const DevScene &S, const Surf &s, v3 d_in, ShadeCtx &sc, Work &wk) {
     const rt_material &m = S.materials[s.material];
     sc.point = s.point; sc.normal = s.normal; sc.d_in = d_in; sc.occlusion_px = 0;
-    sc.view = normalize(-d_in);
     sc.material = s.material; sc.from_outside = s.from_outside;
     sc.color = ld3(S.ambient) * ld3(m.ambient);
     const DevTexture *tex = ((F & F_TEXTURE) && m.texture >= 0) ? &S.textures[m.texture] : nullptr;
@@ -1134,13 +1132,17 @@ template <bool COUNT>
 RT_HD void shade_light(const DevScene &S, ShadeCtx &sc, int l, v3 L, float r, Work &wk) {
     if (COUNT) wk.shade++;
     const rt_material &m = S.materials[sc.material];
-    v3 view = sc.view;
-    v3 R = reflect(-L, sc.normal);
     float NdotL = clamp01(dot(sc.normal, L));
-    float VdotR = clamp01(dot(view, R));
     v3 term = sc.dc * NdotL;
     v3 spec_col = ld3(m.specular);
-    if (spec_col.x != 0.0f || spec_col.y != 0.0f || spec_col.z != 0.0f) term = term + spec_col * shade_pow(VdotR, sc.shininess);
+    // the view vector, the mirrored light direction and the lobe only where the material has a specular term (a
+    // zero coefficient multiplies a finite lobe value: the sum is the same without it)
+    if (spec_col.x != 0.0f || spec_col.y != 0.0f || spec_col.z != 0.0f) {
+        v3 view = normalize(-sc.d_in);
+        v3 R = reflect(-L, sc.normal);
+        float VdotR = clamp01(dot(view, R));
+        term = term + spec_col * shade_pow(VdotR, sc.shininess);
+    }
     r = (r < 0.1f) ? 0.1f : r;
     float inv_r = shade_rcp(r);
     term = ld3(S.light_color + 3 * l) * term;
