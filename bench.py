@@ -38,32 +38,39 @@ WORKLOADS = {
 }
 
 
-def cpu_baseline(preset, width, height, mode, grid_m, max_depth, budget_blocks=None):
-    """Times the CPU oracle on a bounded sample of the same frame: 8x8-pixel blocks on a regular
-    24-pixel lattice (1/9 of the pixels, all taps), traced with OpenMP over all allowed cores."""
+def cpu_baseline(preset, width, height, mode, grid_m, max_depth):
+    """Times the CPU oracle (the restatement of the reference's single-threaded brute-force loop) on bounded samples
+    of the same frame: 8x8-pixel blocks on a regular lattice, all taps.  Once with OpenMP over the allowed cores
+    (blocks every 24 pixels, 1/9 of the frame) and once on one thread, as the reference runs (blocks every 96
+    pixels, 1/144 of the frame)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import numpy as np
     import oracle_lib as O
 
     L = O.lib()
-    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
-    L.orc_set_threads(threads)
     scene = O.Scene(preset)
-    os_, ds_ = [], []
-    step, blk = 24, 8
-    for y0 in range(0, height - blk + 1, step):
-        for x0 in range(0, width - blk + 1, step):
-            o, d, _ = O.camera_rays(width, height, 90.0, mode, grid_m, rect=(x0, y0, x0 + blk, y0 + blk))
-            os_.append(o)
-            ds_.append(d)
-    o, d = np.concatenate(os_), np.concatenate(ds_)
-    t0 = time.perf_counter()
-    _, rays = scene.trace_rays(o, d, max_depth)
-    dt = time.perf_counter() - t0
-    total = int(rays.sum())
-    return {"value": total / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
-            "sample": f"8x8-pixel blocks every 24 px of the {width}x{height} frame "
-                      f"({len(o)} primary rays, {total} rays, {dt:.1f} s)"}
+
+    def sample(step, threads):
+        L.orc_set_threads(threads)
+        os_, ds_ = [], []
+        blk = 8
+        for y0 in range(0, height - blk + 1, step):
+            for x0 in range(0, width - blk + 1, step):
+                o, d, _ = O.camera_rays(width, height, 90.0, mode, grid_m, rect=(x0, y0, x0 + blk, y0 + blk))
+                os_.append(o)
+                ds_.append(d)
+        o, d = np.concatenate(os_), np.concatenate(ds_)
+        t0 = time.perf_counter()
+        _, rays = scene.trace_rays(o, d, max_depth)
+        dt = time.perf_counter() - t0
+        total = int(rays.sum())
+        return total / dt / 1e6, f"8x8-pixel blocks every {step} px of the {width}x{height} frame ({len(o)} primary rays, {total} rays, {dt:.1f} s)"
+
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
+    many, many_sample = sample(24, threads)
+    one, one_sample = sample(96, 1)
+    return {"value": many, "unit": "Mrays/s", "cores": threads, "kind": "port", "sample": many_sample,
+            "single_thread": {"value": one, "unit": "Mrays/s", "cores": 1, "kind": "port", "sample": one_sample}}
 
 
 def launch_ranks(n, argv):
