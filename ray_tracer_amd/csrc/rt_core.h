@@ -185,6 +185,7 @@ constexpr int kOctants = 8;
 // all cones needs no shadow query at all.
 constexpr int kCullMeshes = 4;
 struct alignas(64) LightCull { f4 cone[kCullMeshes]; };
+constexpr uint32_t kUnusedCone = 0x40000000u;  // cos = 2.0f: the slot of a mesh that is not there
 struct BvhNode {
     float lo0[3], hi0[3];
     float lo1[3], hi1[3];
@@ -1232,10 +1233,16 @@ RT_HD void shade_lights(const DevScene &S, bool hit, int accel, Stack &stk, Work
         if (l < 32 && ((S.cullable_lights >> l) & 1u)) {
             u32x16 lc = load_u32x16(S.light_cull + l);
             pin_scalar(lc);
-            float c0 = dot(L, V3(u2f(lc[0]), u2f(lc[1]), u2f(lc[2]))), c1 = dot(L, V3(u2f(lc[4]), u2f(lc[5]), u2f(lc[6])));
-            float c2 = dot(L, V3(u2f(lc[8]), u2f(lc[9]), u2f(lc[10]))), c3 = dot(L, V3(u2f(lc[12]), u2f(lc[13]), u2f(lc[14])));
-            bool in0 = !(c0 < u2f(lc[3])), in1 = !(c1 < u2f(lc[7])), in2 = !(c2 < u2f(lc[11])), in3 = !(c3 < u2f(lc[15]));
-            bool near_mesh = hit & (in0 | in1 | in2 | in3);
+            // slots are filled in order and an unused one holds cos = 2 (never inside): stop at the first
+            bool in = !(dot(L, V3(u2f(lc[0]), u2f(lc[1]), u2f(lc[2]))) < u2f(lc[3]));
+            if (lc[7] != kUnusedCone) {
+                in |= !(dot(L, V3(u2f(lc[4]), u2f(lc[5]), u2f(lc[6]))) < u2f(lc[7]));
+                if (lc[11] != kUnusedCone) {
+                    in |= !(dot(L, V3(u2f(lc[8]), u2f(lc[9]), u2f(lc[10]))) < u2f(lc[11]));
+                    if (lc[15] != kUnusedCone) in |= !(dot(L, V3(u2f(lc[12]), u2f(lc[13]), u2f(lc[14]))) < u2f(lc[15]));
+                }
+            }
+            bool near_mesh = hit & in;
             query = wave_ballot(near_mesh) != 0;  // nothing can lie between these points and the light
         }
         // |L| = 1, so the local ray parameter equals the world distance up to rounding: clip there
