@@ -113,13 +113,43 @@ __global__ void k_bitonic_step(unsigned long long *keys, int n_pow2, int j, int 
     }
 }
 
+// The steps of the same network that stay inside a chunk of kSortChunk keys, in LDS, by one block per chunk:
+// every stage k = 2 .. k_last with all its steps when `whole`, otherwise the steps j < kSortChunk of stage k_last alone
+// (the steps with j >= kSortChunk of that stage were made by k_bitonic_step).
+constexpr int kSortChunk = 4096, kSortThreads = 1024;
+__global__ __launch_bounds__(kSortThreads) void k_bitonic_chunk(unsigned long long *keys, int k_last, int whole) {
+    __shared__ unsigned long long s_keys[kSortChunk];
+    const int base = blockIdx.x * kSortChunk;
+    for (int t = threadIdx.x; t < kSortChunk; t += kSortThreads) s_keys[t] = keys[base + t];
+    __syncthreads();
+    for (int k = whole ? 2 : k_last; k <= k_last; k <<= 1) {
+        for (int j = (k >> 1) < kSortChunk ? (k >> 1) : (kSortChunk >> 1); j > 0; j >>= 1) {
+            for (int t = threadIdx.x; t < kSortChunk / 2; t += kSortThreads) {
+                int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));  // the lower index of the t-th pair of this step
+                unsigned long long a = s_keys[i], b = s_keys[i | j];
+                bool up = ((base + i) & k) == 0;
+                if ((a > b) == up) { s_keys[i] = b; s_keys[i | j] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    for (int t = threadIdx.x; t < kSortChunk; t += kSortThreads) keys[base + t] = s_keys[t];
+}
+
+struct SahJob { int32_t first, last, slot, depth; };  // slot: 2 * parent id + side of the link to fill in, -1 for the root
+
 // sorted position -> triangle record, tie-break key, original triangle and leaf box of the reference
-// at that position (keys == nullptr: identity order)
+// at that position (keys == nullptr: identity order).  With `iota`, also the start of the top-down build:
+// the identity permutation, the root's job and the job counts of every level (one job at level 0).
 __global__ void k_gather_tris(const unsigned long long *keys, int n, int ref_offset, const float *ref_pos, const int32_t *ref_tri,
                               const float *tri_pos, const int32_t *tri_frag, const int32_t *tri_sub, f4 *tri_test,
-                              uint32_t *tri_key, int32_t *tri_orig, float *leaf_box) {
+                              uint32_t *tri_key, int32_t *tri_orig, float *leaf_box, int32_t *iota, SahJob *first_job,
+                              int32_t *level_jobs, int n_levels) {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (iota && k <= n_levels) level_jobs[k] = k == 0 ? 1 : 0;
+    if (iota && k == 0) *first_job = SahJob{0, n - 1, -1, 0};
     if (k >= n) return;
+    if (iota) iota[k] = k;
     int local = keys ? (int)(uint32_t)(keys[k] & 0xffffffffull) : k;
     int orig = ref_tri[ref_offset + local];
     make_tri_test(tri_pos + 9 * (size_t)orig, tri_test + 3 * (size_t)(ref_offset + k));
@@ -128,145 +158,197 @@ __global__ void k_gather_tris(const unsigned long long *keys, int n, int ref_off
     piece_box(ref_pos + 9 * (size_t)(ref_offset + local), leaf_box + 6 * (size_t)(ref_offset + k));
 }
 
-__global__ void k_children(const unsigned long long *keys, int n, int32_t *c0, int32_t *c1) {
+__global__ void k_children(const unsigned long long *keys, int n, int32_t *c0, int32_t *c1, int32_t *node_parent, int32_t *leaf_parent) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n - 1) return;
     int32_t a, b;
     lbvh_node_children(reinterpret_cast<const uint64_t *>(keys), n, i, a, b);
     c0[i] = a;
     c1[i] = b;
+    if (i == 0) node_parent[0] = -1;  // the radix tree's root
+    if (a < 0) leaf_parent[~a] = i; else node_parent[a] = i;
+    if (b < 0) leaf_parent[~b] = i; else node_parent[b] = i;
 }
 
-// Bottom-up fit by ONE workgroup: pass p completes every node whose children were completed in an
-// earlier pass; done_pass[i] holds the pass number (0 = not yet).  All traffic stays inside one CU,
-// so a workgroup barrier is enough to order a pass after the previous one.
-__global__ __launch_bounds__(1024) void k_fit(int n, const int32_t *c0s, const int32_t *c1s, const float *leaf_box, float pad,
-                                              int32_t *done_pass, float *node_lo, float *node_hi, int32_t *height,
-                                              BvhNode *nodes, int32_t root, int32_t *root_height) {
-    __shared__ int s_left;
-    int n_int = n - 1;
-    for (int i = threadIdx.x; i < n_int; i += blockDim.x) done_pass[i] = 0;
-    __syncthreads();
-    for (int pass = 1; pass <= 4096; pass++) {
-        if (threadIdx.x == 0) s_left = 0;
-        __syncthreads();
-        int left = 0;
-        for (int i = threadIdx.x; i < n_int; i += blockDim.x)
-            if (lbvh_fit_node(i, pass, c0s, c1s, leaf_box, pad, done_pass, node_lo, node_hi, height, nodes) == 2) left++;
-        if (left) atomicAdd(&s_left, left);
-        __threadfence_block();
-        __syncthreads();
-        int remaining = s_left;
-        __syncthreads();
-        if (remaining == 0) break;
+// Bottom-up fit, a thread per leaf: each climbs from its leaf's parent; the first to arrive at a node stops, the
+// second (both subtrees are complete then) makes the node and climbs on.  The counter's acquire-release order
+// at device scope makes the first arrival's bounds visible to the second, whichever CU it runs on.  No thread
+// waits for another.  arrived[] starts at zero.
+__global__ void k_fit(int n, const int32_t *c0s, const int32_t *c1s, const int32_t *node_parent, const int32_t *leaf_parent,
+                      const float *leaf_box, float pad, int32_t *arrived, float *node_lo, float *node_hi, int32_t *height,
+                      BvhNode *nodes, int32_t *root_height) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    int cur = leaf_parent[t];
+    for (int step = 0; cur >= 0 && step < n; step++) {  // (a climb is shorter than n; the bound only guards against a broken link)
+        if (__hip_atomic_fetch_add(&arrived[cur], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
+        lbvh_make_node(cur, c0s, c1s, leaf_box, pad, node_lo, node_hi, height, nodes);
+        int up = node_parent[cur];
+        if (up < 0) *root_height = height[cur];
+        cur = up;
     }
-    if (threadIdx.x == 0) *root_height = n_int > 0 ? height[root] : 0;
 }
 
 // ---- top-down build with binned surface-area splits (rt_lbvh.h), one level of the tree per launch.
-// A wave takes one node (a job: a range of the leaf permutation): centre bounds by a strided loop and a
-// wave reduction, bins in the wave's own LDS (integer atomics on order-preserving keys, so the result does
-// not depend on the order of arrival), one lane per candidate split, a 64-bit minimum over (cost, candidate)
-// for the winner, and an order-preserving partition by ballots into the other permutation buffer.  The
-// children's ranges become jobs of the next level; a child that is one leaf is linked at once.
-struct SahJob { int32_t first, last, slot, depth; };  // slot: 2 * parent id + side of the link to fill in, -1 for the root
-constexpr int kSahWaves = 4;
+// A block takes one node (a job: a range of the leaf permutation): centre bounds by a strided loop, a wave
+// reduction and integer atomics in LDS, bins in LDS (integer atomics on order-preserving keys, so the result does
+// not depend on the order of arrival), one lane of wave 0 per candidate split, a 64-bit minimum over (cost,
+// candidate) for the winner, and an order-preserving partition by ballots and a scan over the block's waves into
+// the other permutation buffer.  The children's ranges become jobs of the next level; a child that is one leaf
+// is linked at once.  The first levels have few, long jobs and are launched with large blocks, the later ones
+// with one wave per job; the code is the same.
+constexpr int kSahMaxWaves = 16;
 __device__ __forceinline__ int32_t float_to_ordered(float f) { int32_t i = __float_as_int(f); return i ^ ((i >> 31) & 0x7fffffff); }
 __device__ __forceinline__ float ordered_to_float(int32_t i) { return __int_as_float(i ^ ((i >> 31) & 0x7fffffff)); }
-__device__ __forceinline__ void wave_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
 
-__global__ __launch_bounds__(64 * kSahWaves) void k_sah_level(const SahJob *jobs, int n_jobs, const float *leaf_box, const int32_t *idx_in,
-                                                             int32_t *idx_out, int32_t *c0, int32_t *c1, SahJob *next_jobs,
-                                                             int32_t *next_count, int32_t *root) {
-    __shared__ int32_t s_bins[kSahWaves][3][kSahBins][6];
-    __shared__ int32_t s_cnt[kSahWaves][3][kSahBins];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int j = blockIdx.x * kSahWaves + wave;
-    if (j >= n_jobs) return;  // the whole wave; nothing below synchronises across waves
-    const SahJob job = jobs[j];
+// level_jobs[0] jobs at this level (the grid covers the most a level can have); the next level's are counted in
+// level_jobs[1].  A job of depth d reads the permutation idx[d & 1] and writes the other.  With `finish` a block does
+// not hand the children on but keeps them on a stack of its own and builds the whole subtree of its job: the launch
+// after the levels a balanced tree would need, for what an unbalanced one has left (short ranges).
+constexpr int kSahStack = 64;  // pending siblings, one per level at most: kSahDepthLimit + log2(n) < 64
+__global__ __launch_bounds__(64 * kSahMaxWaves) void k_sah_level(const SahJob *jobs, int32_t *level_jobs, const float *leaf_box, int32_t *idx_even,
+                                                                int32_t *idx_odd, int32_t *c0, int32_t *c1, int32_t *node_parent,
+                                                                int32_t *leaf_parent, SahJob *next_jobs, int32_t *root, int finish) {
+    __shared__ int32_t s_bins[3][kSahBins][6];
+    __shared__ int32_t s_cnt[3][kSahBins];
+    __shared__ int32_t s_centre[6];                 // ordered keys of the centre bounds
+    __shared__ int32_t s_best, s_n_left, s_only[2];
+    __shared__ int32_t s_wave[2][kSahMaxWaves];     // per wave: lefts and rights of the current chunk
+    __shared__ SahJob s_stack[kSahStack];
+    __shared__ int32_t s_sp;
+    const int n_jobs = level_jobs[0];
+    const int j = blockIdx.x;
+    if (j >= n_jobs) return;  // the whole block
+    const int tid = threadIdx.x, nt = blockDim.x, wave = tid >> 6, lane = tid & 63, n_waves = nt >> 6;
+    SahJob job = jobs[j];
+    if (tid == 0) s_sp = 0;
+    for (;;) {
+    const int32_t *idx_in = (job.depth & 1) ? idx_odd : idx_even;
+    int32_t *idx_out = (job.depth & 1) ? idx_even : idx_odd;
     const int len = job.last - job.first + 1;
+    auto for_each_leaf = [&](auto &&body) {  // body(q, box) for the leaves of this thread
+        for (int k = job.first + tid; k <= job.last; k += nt) {
+            int q = idx_in[k];
+            float box[6];
+            for (int c = 0; c < 6; c++) box[c] = leaf_box[6 * q + c];
+            body(q, box);
+        }
+    };
     // centre bounds
+    if (tid < 6) s_centre[tid] = float_to_ordered(tid < 3 ? INFINITY : -INFINITY);
+    __syncthreads();
     float clo[3] = {INFINITY, INFINITY, INFINITY}, chi[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (int k = job.first + lane; k <= job.last; k += 64) {
-        int q = idx_in[k];
-        for (int a = 0; a < 3; a++) { float c = sah_centre(leaf_box, q, a); clo[a] = fminf(clo[a], c); chi[a] = fmaxf(chi[a], c); }
-    }
+    for_each_leaf([&](int, const float *box) {
+        for (int a = 0; a < 3; a++) { float c = 0.5f * (box[a] + box[3 + a]); clo[a] = fminf(clo[a], c); chi[a] = fmaxf(chi[a], c); }
+    });
     for (int off = 32; off >= 1; off >>= 1)
         for (int a = 0; a < 3; a++) { clo[a] = fminf(clo[a], __shfl_xor(clo[a], off)); chi[a] = fmaxf(chi[a], __shfl_xor(chi[a], off)); }
+    if (lane == 0)
+        for (int a = 0; a < 3; a++) { atomicMin(&s_centre[a], float_to_ordered(clo[a])); atomicMax(&s_centre[3 + a], float_to_ordered(chi[a])); }
+    __syncthreads();
+    for (int a = 0; a < 3; a++) { clo[a] = ordered_to_float(s_centre[a]); chi[a] = ordered_to_float(s_centre[3 + a]); }
     float ext[3];
     bool usable[3];
     for (int a = 0; a < 3; a++) { ext[a] = chi[a] - clo[a]; usable[a] = ext[a] > 0 && ext[a] < INFINITY; }
     int best = -1;      // winning candidate: axis * (kSahBins - 1) + bin, -1: split at the median
     int32_t n_left = 0;
-    if (job.depth < kSahDepthLimit && (usable[0] || usable[1] || usable[2])) {
-        int32_t *bins = &s_bins[wave][0][0][0], *cnt = &s_cnt[wave][0][0];
-        for (int i = lane; i < 3 * kSahBins * 6; i += 64) bins[i] = float_to_ordered((i % 6) < 3 ? INFINITY : -INFINITY);
-        for (int i = lane; i < 3 * kSahBins; i += 64) cnt[i] = 0;
-        wave_lds_fence();
-        for (int k = job.first + lane; k <= job.last; k += 64) {
-            int q = idx_in[k];
+    if (job.depth < kSahDepthLimit && (usable[0] || usable[1] || usable[2])) {  // (block-uniform)
+        int32_t *bins = &s_bins[0][0][0], *cnt = &s_cnt[0][0];
+        for (int i = tid; i < 3 * kSahBins * 6; i += nt) bins[i] = float_to_ordered((i % 6) < 3 ? INFINITY : -INFINITY);
+        for (int i = tid; i < 3 * kSahBins; i += nt) cnt[i] = 0;
+        if (tid == 0) s_best = -1;
+        __syncthreads();
+        for_each_leaf([&](int, const float *box) {
             for (int a = 0; a < 3; a++) {
                 if (!usable[a]) continue;
-                int b = sah_bin(sah_centre(leaf_box, q, a), clo[a], ext[a]);
+                int b = sah_bin(0.5f * (box[a] + box[3 + a]), clo[a], ext[a]);
                 for (int c = 0; c < 3; c++) {
-                    float lo = leaf_box[6 * q + c], hi = leaf_box[6 * q + 3 + c];
-                    if (lo == lo) atomicMin(&s_bins[wave][a][b][c], float_to_ordered(lo));  // fminf / fmaxf skip a NaN
-                    if (hi == hi) atomicMax(&s_bins[wave][a][b][3 + c], float_to_ordered(hi));
+                    float lo = box[c], hi = box[3 + c];
+                    if (lo == lo) atomicMin(&s_bins[a][b][c], float_to_ordered(lo));  // fminf / fmaxf skip a NaN
+                    if (hi == hi) atomicMax(&s_bins[a][b][3 + c], float_to_ordered(hi));
                 }
-                atomicAdd(&s_cnt[wave][a][b], 1);
+                atomicAdd(&s_cnt[a][b], 1);
             }
-        }
-        wave_lds_fence();
-        for (int i = lane; i < 3 * kSahBins * 6; i += 64) bins[i] = __float_as_int(ordered_to_float(bins[i]));
-        wave_lds_fence();
-        unsigned long long key = ~0ull;
-        int32_t my_left = 0;
-        if (lane < 3 * (kSahBins - 1)) {
-            int a = lane / (kSahBins - 1), b = lane % (kSahBins - 1);
-            if (usable[a]) {
-                float cost = sah_split_cost(reinterpret_cast<const float *>(&s_bins[wave][a][0][0]), &s_cnt[wave][a][0], b, my_left);
-                if (cost < INFINITY) key = ((unsigned long long)(uint32_t)__float_as_int(cost) << 32) | (unsigned long long)lane;
+        });
+        __syncthreads();
+        for (int i = tid; i < 3 * kSahBins * 6; i += nt) bins[i] = __float_as_int(ordered_to_float(bins[i]));
+        __syncthreads();
+        if (wave == 0) {
+            unsigned long long key = ~0ull;
+            int32_t my_left = 0;
+            if (lane < 3 * (kSahBins - 1)) {
+                int a = lane / (kSahBins - 1), b = lane % (kSahBins - 1);
+                if (usable[a]) {
+                    float cost = sah_split_cost(reinterpret_cast<const float *>(&s_bins[a][0][0]), &s_cnt[a][0], b, my_left);
+                    if (cost < INFINITY) key = ((unsigned long long)(uint32_t)__float_as_int(cost) << 32) | (unsigned long long)lane;
+                }
             }
+            unsigned long long m = key;
+            for (int off = 32; off >= 1; off >>= 1) {
+                unsigned long long o = __shfl_xor(m, off);
+                m = o < m ? o : m;
+            }
+            if (m != ~0ull && lane == (int)(m & 0xffffffffull)) { s_best = lane; s_n_left = my_left; }
         }
-        unsigned long long m = key;
-        for (int off = 32; off >= 1; off >>= 1) {
-            unsigned long long o = __shfl_xor(m, off);
-            m = o < m ? o : m;
-        }
-        if (m != ~0ull) {
-            best = (int)(m & 0xffffffffull);
-            n_left = __shfl(my_left, best);
-        }
+        __syncthreads();
+        best = s_best;
+        n_left = best < 0 ? 0 : s_n_left;
     }
     const int32_t total_left = best < 0 ? (len + 1) / 2 : n_left;
     const int axis = best < 0 ? 0 : best / (kSahBins - 1), bin = best < 0 ? 0 : best % (kSahBins - 1);
     const float lo_a = axis == 0 ? clo[0] : axis == 1 ? clo[1] : clo[2], ext_a = axis == 0 ? ext[0] : axis == 1 ? ext[1] : ext[2];
-    // order-preserving partition into the other buffer
+    // order-preserving partition into the other buffer, a chunk of one element per thread at a time
     int lbase = job.first, rbase = job.first + total_left;
-    int32_t only_left = 0, only_right = 0;
-    for (int k0 = job.first; k0 <= job.last; k0 += 64) {
-        int k = k0 + lane;
+    auto place = [&](int k, int q, float centre) {  // the block's threads hold the leaves k0 .. k0 + nt - 1 of the range, in order
         bool act = k <= job.last;
-        int q = act ? idx_in[k] : 0;
-        bool left = act && (best < 0 ? (k - job.first) < total_left : sah_bin(sah_centre(leaf_box, q, axis), lo_a, ext_a) <= bin);
+        bool left = act && (best < 0 ? (k - job.first) < total_left : sah_bin(centre, lo_a, ext_a) <= bin);
         bool right = act && !left;
         unsigned long long ml = __builtin_amdgcn_ballot_w64(left), mr = __builtin_amdgcn_ballot_w64(right);
+        if (lane == 0) { s_wave[0][wave] = __popcll(ml); s_wave[1][wave] = __popcll(mr); }
+        __syncthreads();
+        int lsum = 0, rsum = 0, lmine = 0, rmine = 0;
+        for (int w = 0; w < n_waves; w++) {
+            if (w == wave) { lmine = lsum; rmine = rsum; }
+            lsum += s_wave[0][w]; rsum += s_wave[1][w];
+        }
         unsigned long long below = (1ull << lane) - 1ull;
-        if (left) idx_out[lbase + __popcll(ml & below)] = q;
-        if (right) idx_out[rbase + __popcll(mr & below)] = q;
-        if (ml) only_left = __shfl(q, __ffsll((long long)ml) - 1);
-        if (mr) only_right = __shfl(q, 63 - __clzll((long long)mr));
-        lbase += __popcll(ml); rbase += __popcll(mr);
+        if (left) idx_out[lbase + lmine + __popcll(ml & below)] = q;
+        if (right) idx_out[rbase + rmine + __popcll(mr & below)] = q;
+        if (left && total_left == 1) s_only[0] = q;          // the one leaf of a side (one writer)
+        if (right && len - total_left == 1) s_only[1] = q;
+        lbase += lsum; rbase += rsum;
+        __syncthreads();
+    };
+    for (int k0 = job.first; k0 <= job.last; k0 += nt) {
+        int k = k0 + tid;
+        int q = k <= job.last ? idx_in[k] : 0;
+        place(k, q, sah_centre(leaf_box, q, axis));
     }
-    if (lane != 0) return;
-    const int32_t g = job.first + total_left - 1;  // this node's id
-    if (job.slot < 0) *root = g;
-    else if (job.slot & 1) c1[job.slot >> 1] = g;
-    else c0[job.slot >> 1] = g;
-    if (total_left == 1) c0[g] = ~only_left;
-    else { SahJob nj = {job.first, g, 2 * g, job.depth + 1}; next_jobs[atomicAdd(next_count, 1)] = nj; }
-    if (len - total_left == 1) c1[g] = ~only_right;
-    else { SahJob nj = {g + 1, job.last, 2 * g + 1, job.depth + 1}; next_jobs[atomicAdd(next_count, 1)] = nj; }
+    if (tid == 0) {
+        int32_t *next_count = level_jobs + 1;
+        const int32_t g = job.first + total_left - 1;  // this node's id
+        if (job.slot < 0) { *root = g; node_parent[g] = -1; }
+        else {
+            if (job.slot & 1) c1[job.slot >> 1] = g; else c0[job.slot >> 1] = g;
+            node_parent[g] = job.slot >> 1;
+        }
+        SahJob kids[2] = {{job.first, g, 2 * g, job.depth + 1}, {g + 1, job.last, 2 * g + 1, job.depth + 1}};
+        if (total_left == 1) { c0[g] = ~s_only[0]; leaf_parent[s_only[0]] = g; }
+        if (len - total_left == 1) { c1[g] = ~s_only[1]; leaf_parent[s_only[1]] = g; }
+        for (int side = 1; side >= 0; side--) {  // (the left child ends on top of the stack)
+            if ((side == 0 ? total_left : len - total_left) == 1) continue;
+            if (!finish) next_jobs[atomicAdd(next_count, 1)] = kids[side];
+            else if (s_sp < kSahStack) s_stack[s_sp++] = kids[side];
+            else level_jobs[2] = 1;  // cannot happen: reported as an unfinished build
+        }
+    }
+    if (!finish) return;
+    __syncthreads();
+    if (s_sp == 0) return;  // (block-uniform)
+    job = s_stack[s_sp - 1];
+    __syncthreads();
+    if (tid == 0) s_sp--;
+    }
 }
 
 // ------------------------------------------------------------------ render kernels
@@ -1020,7 +1102,7 @@ extern "C" int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *sc) {
         if (m.tri_count <= 0) continue;
         hipLaunchKernelGGL(k_gather_tris, dim3((m.tri_count + 255) / 256), dim3(256), 0, ctx->stream, nullptr, m.tri_count,
                            m.tri_offset, ctx->d_ref_pos, ctx->d_ref_tri, ctx->d_tri_pos, ctx->d_tri_frag, ctx->d_tri_sub,
-                           ctx->d_tri_test, ctx->d_tri_key, ctx->d_tri_orig, ctx->d_leaf_box);
+                           ctx->d_tri_test, ctx->d_tri_key, ctx->d_tri_orig, ctx->d_leaf_box, nullptr, nullptr, nullptr, 0);
     }
     RT_HIP(hipGetLastError());
 
@@ -1127,13 +1209,17 @@ extern "C" int rt_build_accel(rt_ctx *ctx) {
     RT_HIP(hipSetDevice(ctx->device));
     int max_n = 0;
     for (const DevMesh &m : ctx->meshes) max_n = std::max(max_n, m.tri_count);
-    int max_pow2 = 1;
+    int max_pow2 = kSortChunk;  // the sort works on whole chunks
     while (max_pow2 < max_n) max_pow2 <<= 1;
+    int max_levels = 2;         // height of the top-down tree: kSahDepthLimit + log2(n) at most (rt_lbvh.h)
+    for (int v = 1; v < max_n; v <<= 1) max_levels++;
+    max_levels += kSahDepthLimit;
     unsigned long long *d_keys = nullptr;
-    int32_t *d_c0 = nullptr, *d_c1 = nullptr, *d_done = nullptr, *d_height = nullptr, *d_root = nullptr;
+    int32_t *d_c0 = nullptr, *d_c1 = nullptr, *d_done = nullptr, *d_height = nullptr, *d_root = nullptr, *d_root_id = nullptr;
     float *d_lo = nullptr, *d_hi = nullptr, *d_bounds = nullptr;
-    int32_t *d_idx[2] = {nullptr, nullptr}, *d_sah_count = nullptr;
+    int32_t *d_idx[2] = {nullptr, nullptr}, *d_level_jobs = nullptr, *d_node_parent = nullptr, *d_leaf_parent = nullptr;
     SahJob *d_jobs[2] = {nullptr, nullptr};
+    const size_t n_meshes = ctx->meshes.size();
     int rc;
     std::vector<void *> tmp;
     auto cleanup = [&]() { for (void *p : tmp) (void)hipFree(p); };
@@ -1145,71 +1231,79 @@ extern "C" int rt_build_accel(rt_ctx *ctx) {
     TMP_ALLOC(d_c1, (size_t)max_n);
     TMP_ALLOC(d_done, (size_t)max_n);
     TMP_ALLOC(d_height, (size_t)max_n);
-    TMP_ALLOC(d_root, (size_t)ctx->meshes.size() + 1);
+    TMP_ALLOC(d_node_parent, (size_t)max_n);
+    TMP_ALLOC(d_leaf_parent, (size_t)max_n);
+    TMP_ALLOC(d_root, n_meshes + 1);
+    TMP_ALLOC(d_root_id, n_meshes + 1);
     TMP_ALLOC(d_lo, 3 * (size_t)max_n);
     TMP_ALLOC(d_hi, 3 * (size_t)max_n);
-    TMP_ALLOC(d_bounds, 6 * (size_t)ctx->meshes.size() + 6);
+    TMP_ALLOC(d_bounds, 6 * n_meshes + 6);
     if (!ctx->radix_tree) {
         TMP_ALLOC(d_idx[0], (size_t)max_n);
         TMP_ALLOC(d_idx[1], (size_t)max_n);
         TMP_ALLOC(d_jobs[0], (size_t)max_n);
         TMP_ALLOC(d_jobs[1], (size_t)max_n);
-        TMP_ALLOC(d_sah_count, 2);
+        TMP_ALLOC(d_level_jobs, (size_t)(max_levels + 2) * (n_meshes + 1));  // a row per mesh: the last count of each is checked at the end
     }
 #undef TMP_ALLOC
-    std::vector<float> bounds(6 * ctx->meshes.size() + 6, 0.0f);
-    for (size_t i = 0; i < ctx->meshes.size(); i++)
+    std::vector<float> bounds(6 * n_meshes + 6, 0.0f);
+    for (size_t i = 0; i < n_meshes; i++)
         for (int a = 0; a < 3; a++) { bounds[6 * i + a] = ctx->mesh_build[i].lo[a]; bounds[6 * i + 3 + a] = ctx->mesh_build[i].hi[a]; }
     hipError_t e = hipMemcpyAsync(d_bounds, bounds.data(), bounds.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(d_root_id, 0, (n_meshes + 1) * sizeof(int32_t), ctx->stream);  // the radix tree's root is node 0
+    if (e == hipSuccess) e = hipMemsetAsync(d_root, 0, (n_meshes + 1) * sizeof(int32_t), ctx->stream);
+    if (e == hipSuccess && d_level_jobs) e = hipMemsetAsync(d_level_jobs, 0, (size_t)(max_levels + 2) * (n_meshes + 1) * sizeof(int32_t), ctx->stream);
     if (e != hipSuccess) { cleanup(); return fail(ctx, RT_ERR_HIP, hipGetErrorString(e)); }
 
-    std::vector<int32_t> iota(max_n);  // outlives every copy queued from it
-    for (int k = 0; k < max_n; k++) iota[k] = k;
-    std::vector<SahJob> first_jobs(ctx->meshes.size());
+    // Everything below is queued without waiting for the device: the number of jobs of a level stays there.
+    std::vector<int> unfinished_at(n_meshes, -1);  // per mesh: the entry of its row of d_level_jobs that must still be zero at the end
     (void)hipEventRecord(ctx->ev0, ctx->stream);
-    for (size_t i = 0; i < ctx->meshes.size(); i++) {
+    for (size_t i = 0; i < n_meshes; i++) {
         const DevMesh &m = ctx->meshes[i];
         int n = m.tri_count;
         if (n <= 0) continue;
-        int n_pow2 = 1;
+        int n_pow2 = kSortChunk;
         while (n_pow2 < n) n_pow2 <<= 1;
         dim3 blk(256), grd((n_pow2 + 255) / 256);
         hipLaunchKernelGGL(k_sort_keys, grd, blk, 0, ctx->stream, ctx->d_ref_pos + 9 * (size_t)m.tri_offset, n, n_pow2,
                            d_bounds + 6 * i, d_bounds + 6 * i + 3, d_keys);
-        for (int k = 2; k <= n_pow2; k <<= 1)
-            for (int j = k >> 1; j > 0; j >>= 1)
+        hipLaunchKernelGGL(k_bitonic_chunk, dim3(n_pow2 / kSortChunk), dim3(kSortThreads), 0, ctx->stream, d_keys, kSortChunk, 1);
+        for (int k = 2 * kSortChunk; k <= n_pow2; k <<= 1) {
+            for (int j = k >> 1; j >= kSortChunk; j >>= 1)
                 hipLaunchKernelGGL(k_bitonic_step, grd, blk, 0, ctx->stream, d_keys, n_pow2, j, k);
+            hipLaunchKernelGGL(k_bitonic_chunk, dim3(n_pow2 / kSortChunk), dim3(kSortThreads), 0, ctx->stream, d_keys, k, 0);
+        }
+        const bool top_down = !ctx->radix_tree && n >= 2;
+        int32_t *level_jobs = top_down ? d_level_jobs + (size_t)(max_levels + 2) * i : nullptr;
         hipLaunchKernelGGL(k_gather_tris, dim3((n + 255) / 256), blk, 0, ctx->stream, d_keys, n, m.tri_offset, ctx->d_ref_pos,
                            ctx->d_ref_tri, ctx->d_tri_pos, ctx->d_tri_frag, ctx->d_tri_sub, ctx->d_tri_test, ctx->d_tri_key,
-                           ctx->d_tri_orig, ctx->d_leaf_box);
+                           ctx->d_tri_orig, ctx->d_leaf_box, top_down ? d_idx[0] : nullptr, d_jobs[0], level_jobs, max_levels);
         if (n >= 2) {
-            int32_t root = 0;
             if (ctx->radix_tree) {
-                hipLaunchKernelGGL(k_children, dim3((n + 255) / 256), blk, 0, ctx->stream, d_keys, n, d_c0, d_c1);
+                hipLaunchKernelGGL(k_children, dim3((n + 255) / 256), blk, 0, ctx->stream, d_keys, n, d_c0, d_c1, d_node_parent, d_leaf_parent);
             } else {
-                // top-down, one launch per level; the number of jobs of the next level comes back each time
-                first_jobs[i] = SahJob{0, n - 1, -1, 0};
-                e = hipMemcpyAsync(d_idx[0], iota.data(), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream);
-                if (e == hipSuccess) e = hipMemcpyAsync(d_jobs[0], &first_jobs[i], sizeof(SahJob), hipMemcpyHostToDevice, ctx->stream);
-                int n_jobs = 1, cur = 0;
-                for (int level = 0; e == hipSuccess && n_jobs > 0; level++, cur ^= 1) {
-                    if (level > kSahDepthLimit + 40) { e = hipErrorUnknown; break; }  // cannot happen: the height is bounded
-                    e = hipMemsetAsync(d_sah_count, 0, sizeof(int32_t), ctx->stream);
-                    if (e != hipSuccess) break;
-                    hipLaunchKernelGGL(k_sah_level, dim3((n_jobs + kSahWaves - 1) / kSahWaves), dim3(64 * kSahWaves), 0, ctx->stream,
-                                       d_jobs[cur], n_jobs, ctx->d_leaf_box + 6 * (size_t)m.tri_offset, d_idx[cur], d_idx[cur ^ 1], d_c0, d_c1,
-                                       d_jobs[cur ^ 1], d_sah_count, d_sah_count + 1);
-                    e = hipMemcpyAsync(&n_jobs, d_sah_count, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream);
-                    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+                // top-down, one launch per level for the levels a balanced tree has and two more, then one launch
+                // that finishes what is left.  A level has at most min(2^level, n / 2) jobs: each covers two
+                // leaves or more of its own.
+                int levels = 2;
+                for (int v = 1; v < n; v <<= 1) levels++;
+                for (int level = 0; level <= levels; level++) {
+                    const bool finish = level == levels;
+                    long long most = level < 30 ? std::min<long long>(1ll << level, n / 2) : n / 2;
+                    // a job of this level has n / 2^level leaves if the tree is balanced; no more than four per thread then
+                    int waves = 1;
+                    while (!finish && waves < kSahMaxWaves && (long long)waves * 256 * (1ll << std::min(level, 30)) < n) waves <<= 1;
+                    hipLaunchKernelGGL(k_sah_level, dim3((unsigned)most), dim3(64 * waves), 0, ctx->stream,
+                                       d_jobs[level & 1], level_jobs + level, ctx->d_leaf_box + 6 * (size_t)m.tri_offset, d_idx[0], d_idx[1],
+                                       d_c0, d_c1, d_node_parent, d_leaf_parent, d_jobs[(level & 1) ^ 1], d_root_id + i, finish ? 1 : 0);
                 }
-                if (e == hipSuccess) e = hipMemcpy(&root, d_sah_count + 1, sizeof(int32_t), hipMemcpyDeviceToHost);
-                if (e != hipSuccess) break;
+                unfinished_at[i] = levels + 2;
             }
-            ctx->mesh_build[i].root = root;
-            ctx->meshes[i].root = root;
-            hipLaunchKernelGGL(k_fit, dim3(1), dim3(1024), 0, ctx->stream, n, d_c0, d_c1,
+            e = hipMemsetAsync(d_done, 0, (size_t)n * sizeof(int32_t), ctx->stream);
+            if (e != hipSuccess) break;
+            hipLaunchKernelGGL(k_fit, dim3((n + 255) / 256), blk, 0, ctx->stream, n, d_c0, d_c1, d_node_parent, d_leaf_parent,
                                ctx->d_leaf_box + 6 * (size_t)m.tri_offset, ctx->mesh_build[i].pad, d_done, d_lo, d_hi, d_height,
-                               ctx->d_nodes + m.node_offset, root, d_root + i);
+                               ctx->d_nodes + m.node_offset, d_root + i);
             int nv = (n - 1) * (kOctants - 1);
             hipLaunchKernelGGL(k_octant_variants, dim3((nv + 255) / 256), blk, 0, ctx->stream, ctx->d_nodes + m.node_offset, n - 1);
             hipLaunchKernelGGL(k_octant_variant0, dim3((n - 1 + 255) / 256), blk, 0, ctx->stream, ctx->d_nodes + m.node_offset, n - 1);
@@ -1219,12 +1313,22 @@ extern "C" int rt_build_accel(rt_ctx *ctx) {
     ctx->trace_timed = false;
     if (e == hipSuccess) e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    if (e == hipSuccess)  // the roots
-        e = hipMemcpy(ctx->d_meshes, ctx->meshes.data(), ctx->meshes.size() * sizeof(DevMesh), hipMemcpyHostToDevice);
-    std::vector<int32_t> roots(ctx->meshes.size() + 1, 0);
+    std::vector<int32_t> roots(n_meshes + 1, 0), root_ids(n_meshes + 1, 0);
     if (e == hipSuccess) e = hipMemcpy(roots.data(), d_root, roots.size() * sizeof(int32_t), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(root_ids.data(), d_root_id, root_ids.size() * sizeof(int32_t), hipMemcpyDeviceToHost);
+    bool unfinished = false;
+    if (e == hipSuccess && d_level_jobs) {  // cannot happen: the height is bounded
+        std::vector<int32_t> counts((size_t)(max_levels + 2) * (n_meshes + 1));
+        e = hipMemcpy(counts.data(), d_level_jobs, counts.size() * sizeof(int32_t), hipMemcpyDeviceToHost);
+        for (size_t i = 0; i < n_meshes; i++)
+            unfinished = unfinished || (unfinished_at[i] >= 0 && counts[(size_t)(max_levels + 2) * i + unfinished_at[i]] != 0);
+    }
+    for (size_t i = 0; i < n_meshes; i++) { ctx->mesh_build[i].root = root_ids[i]; ctx->meshes[i].root = root_ids[i]; }
+    if (e == hipSuccess)  // the roots
+        e = hipMemcpy(ctx->d_meshes, ctx->meshes.data(), n_meshes * sizeof(DevMesh), hipMemcpyHostToDevice);
     cleanup();
     if (e != hipSuccess) return fail(ctx, RT_ERR_HIP, std::string("tree build: ") + hipGetErrorString(e));
+    if (unfinished) return fail(ctx, RT_ERR_LIMIT, "tree build: levels left over");
     (void)hipEventElapsedTime(&ctx->last_build_ms, ctx->ev0, ctx->ev1);
     ctx->bvh_max_depth = 0;
     for (size_t i = 0; i < ctx->meshes.size(); i++) {

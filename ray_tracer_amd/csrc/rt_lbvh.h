@@ -142,17 +142,11 @@ RT_HD float sah_split_cost(const float *bins, const int32_t *counts, int b, int3
     return (c == c) ? c : INFINITY;
 }
 
-// One fitting pass over internal node i.  done_pass[i] is 0 until the node is completed and then
-// holds the number of the pass that completed it.  A node may be completed in pass `pass` once each
-// child is a leaf or was completed in an EARLIER pass (so its bounds are already in memory).
-// Returns 0: was already done, 1: completed now, 2: still waiting.
-RT_HD int lbvh_fit_node(int i, int pass, const int32_t *c0s, const int32_t *c1s, const float *leaf_box, float pad,
-                        int32_t *done_pass, float *node_lo, float *node_hi, int32_t *height, BvhNode *nodes) {
-    if (done_pass[i]) return 0;
+// Internal node i from its children: the record with both children's boxes, the node's own bounds and height.
+// Each child is a leaf or a node whose bounds and height are already in memory.
+RT_HD void lbvh_make_node(int i, const int32_t *c0s, const int32_t *c1s, const float *leaf_box, float pad,
+                          float *node_lo, float *node_hi, int32_t *height, BvhNode *nodes) {
     int32_t c0 = c0s[i], c1 = c1s[i];
-    int d0 = c0 < 0 ? 0 : done_pass[c0], d1 = c1 < 0 ? 0 : done_pass[c1];
-    bool r0 = c0 < 0 || (d0 != 0 && d0 < pass), r1 = c1 < 0 || (d1 != 0 && d1 < pass);
-    if (!(r0 && r1)) return 2;
     BvhNode nd;
     int h0 = 0, h1 = 0;
     if (c0 < 0) leaf_bounds(leaf_box, ~c0, pad, nd.lo0, nd.hi0);
@@ -166,6 +160,20 @@ RT_HD int lbvh_fit_node(int i, int pass, const int32_t *c0s, const int32_t *c1s,
     }
     height[i] = 1 + (h0 > h1 ? h0 : h1);
     nodes[i] = nd;
+}
+
+// One fitting pass over internal node i.  done_pass[i] is 0 until the node is completed and then
+// holds the number of the pass that completed it.  A node may be completed in pass `pass` once each
+// child is a leaf or was completed in an EARLIER pass (so its bounds are already in memory).
+// Returns 0: was already done, 1: completed now, 2: still waiting.
+RT_HD int lbvh_fit_node(int i, int pass, const int32_t *c0s, const int32_t *c1s, const float *leaf_box, float pad,
+                        int32_t *done_pass, float *node_lo, float *node_hi, int32_t *height, BvhNode *nodes) {
+    if (done_pass[i]) return 0;
+    int32_t c0 = c0s[i], c1 = c1s[i];
+    int d0 = c0 < 0 ? 0 : done_pass[c0], d1 = c1 < 0 ? 0 : done_pass[c1];
+    bool r0 = c0 < 0 || (d0 != 0 && d0 < pass), r1 = c1 < 0 || (d1 != 0 && d1 < pass);
+    if (!(r0 && r1)) return 2;
+    lbvh_make_node(i, c0s, c1s, leaf_box, pad, node_lo, node_hi, height, nodes);
     done_pass[i] = pass;
     return 1;
 }
