@@ -147,7 +147,7 @@ typedef struct {
     int32_t grid_m;    /* RT_MODE_GRID only                                           */
     int32_t max_depth; /* rays deeper than this are not traced; the reference is unbounded */
     int32_t accel;     /* RT_ACCEL_*                                                  */
-    int32_t rank;      /* this context renders the tiles t with t % world_size == rank */
+    int32_t rank;      /* this context renders local tile q = tile q * world_size + (rank + q) % world_size, q = 0, 1, ... */
     int32_t world_size;
     int32_t count_work; /* non-zero: also count intersection tests (slower kernel variant) */
     int32_t kernel;     /* RT_KERNEL_*: which render kernel; they all write the same pixels */

@@ -15,7 +15,7 @@ for world in (1, 2, 4, 8):
     times, variants = [], []
     for rank in range(world):
         p = ctx.params(w, h, mode=rt.MODE_GRID, grid_m=4, rank=rank, world_size=world)
-        for _ in range(9):  # every kernel variant worth trying has been timed after these: the fastest runs from here on
+        for _ in range(3):  # warm-up; the per-tile kernel also needs one frame of tile times
             ctx.render_shard_device(p, None, buf.data_ptr())
             torch.cuda.synchronize()
         evs = []

@@ -353,13 +353,22 @@ __global__ __launch_bounds__(64 * kSahMaxWaves) void k_sah_level(const SahJob *j
 
 // ------------------------------------------------------------------ render kernels
 
+// Which tile of the frame (row-major) is local tile `local` of a rank: the tiles are dealt in groups of world_size
+// consecutive tiles, one to each rank, and the deal rotates by one from group to group.  Without the rotation a
+// rank's tiles are the same columns of every row whenever the row length is a multiple of the world size, and
+// the ranks' shares of a frame differ by what those columns show (measured on the teapot frame at 8 ranks:
+// shares between 0.406 and 0.447 ms).
+__host__ __device__ inline int shard_tile(int local, int rank, int world_size) {
+    return local * world_size + (rank + local) % world_size;
+}
+
 struct RenderArgs {
     int32_t width, height, mode, grid_m, max_depth, accel, rank, world_size;
     int32_t tiles_x, tiles_total;
     Camera cam;
 };
 
-// Block b renders local tile b = global tile b * world_size + rank.  Each wave owns an 8x8 pixel
+// Block b renders local tile b = global tile shard_tile(b, rank, world_size).  Each wave owns an 8x8 pixel
 // quadrant of the 16x16 tile so that its 64 rays are spatially coherent.
 // copies of the fitted tree for the ray-direction octants 1..7 (variant 0 is what k_fit wrote)
 __global__ void k_octant_variants(BvhNode *nodes, int n) {
@@ -379,7 +388,7 @@ __global__ void k_octant_variant0(BvhNode *nodes, int n) {
 template <int F, bool COUNT>
 __device__ __forceinline__ void render_tile(const DevScene &S, const RenderArgs &a, int local, WaveStack &stk, const float *grid_off,
                                             float *rgb_tiles, uint8_t *rgb8_tiles, Work &wk) {
-    int tile = local * a.world_size + a.rank;
+    int tile = shard_tile(local, a.rank, a.world_size);
     int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     int px = (wave & 1) * 8 + (lane & 7), py = (wave >> 1) * 8 + (lane >> 3);
     int i = (tile % a.tiles_x) * RT_TILE_W + px, j = (tile / a.tiles_x) * RT_TILE_H + py;
@@ -468,7 +477,7 @@ template <int F>
 __device__ __forceinline__ void render_item(const DevScene &S, const RenderArgs &a, int local, int part, WaveStack &stk, const float *grid_off,
                                             float *tap_lds, float *rgb_tiles, uint8_t *rgb8_tiles, Work &wk) {
     const bool whole = part < 0;  // (block-uniform)
-    const int tile = local * a.world_size + a.rank;
+    const int tile = shard_tile(local, a.rank, a.world_size);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int quad = whole ? wave : part;
     const int px = (quad & 1) * 8 + (lane & 7), py = (quad >> 1) * 8 + (lane >> 3);
@@ -521,7 +530,7 @@ __device__ __forceinline__ void render_tile_part(const DevScene &S, const Render
                                                  const float *grid_off, float *tap_lds, float *rgb_tiles, uint8_t *rgb8_tiles, Work &wk) {
     constexpr int PX = 64 / PH;  // pixels of a block
     const int quad = part / PH, sub = part % PH;
-    const int tile = local * a.world_size + a.rank;
+    const int tile = shard_tile(local, a.rank, a.world_size);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int pl = lane % PX, phase = lane / PX;  // this lane's pixel of the block and which of the wave's PH taps it traces
     const int q = sub * PX + pl;                  // pixel of the quadrant, row-major
@@ -784,7 +793,7 @@ __global__ void k_untile(const T *shards, T *frame, int width, int height, int t
     int within = (int)(idx % kTileChunks);
     size_t tl = idx / kTileChunks;
     int local = (int)(tl % tiles_per_rank), r = (int)(tl / tiles_per_rank) + first_rank;
-    int tile = local * world_size + r;
+    int tile = shard_tile(local, r, world_size);
     if (tile >= tiles_total) return;
     int row = within / kChunks, part = within % kChunks;
     int x0 = (tile % tiles_x) * RT_TILE_W, y = (tile / tiles_x) * RT_TILE_H + row;
@@ -1447,7 +1456,8 @@ static int render_shard(rt_ctx *ctx, const rt_render_params *p, float *d_rgb_til
     int ty = (p->height + RT_TILE_H - 1) / RT_TILE_H;
     a.tiles_total = a.tiles_x * ty;
     a.cam = make_camera(p->width, p->height, p->fov);
-    const int local_tiles = (a.tiles_total - p->rank + p->world_size - 1) / p->world_size;  // tiles t = b*W + rank < total
+    // one tile of every group of world_size tiles (shard_tile); in the last group it may lie past the frame: its block leaves at once
+    const int local_tiles = (a.tiles_total + p->world_size - 1) / p->world_size;
     if (local_tiles <= 0) return RT_OK;
     const bool timed_tiles = variant == 3 || variant == kVariantQueue;
     if (timed_tiles) {
