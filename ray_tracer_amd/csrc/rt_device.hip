@@ -41,12 +41,13 @@ constexpr int kCounterStripes = 4096, kCounterStride = 16;
 // The mesh-only variant fits 96 registers and the quadric-only variant 80 without spilling (a sixth wave did not pay); the
 // others need more than 100.
 constexpr int render_waves(int features, bool count) {
-    // mesh-only scenes: 6 waves (80 vector registers, 19 of the pixel loop's values in scratch) beat 5 (96, none spilled) by 2 %
-    // and 4 by 15 %: the walk waits for its scalar loads, and only other waves fill that time
-    return count ? 4 : features == 0 ? 8 : features == F_MESH ? 6 : features == (F_QUADRIC | F_SECONDARY) ? 5 : 4;
+    // mesh-only scenes: 5 waves (96 vector registers, none spilled).  6 waves (80 registers, 19 values of the pixel loop in
+    // scratch) are 2 % faster, the walk waits for its scalar loads and only other waves fill that time, but write 470 MB of
+    // scratch per 4K frame to HBM against 25 MB of pixels; 4 waves are 13 % slower.
+    return count ? 4 : features == 0 ? 8 : features == F_MESH ? 5 : features == (F_QUADRIC | F_SECONDARY) ? 5 : 4;
 }
 // (the kernels with two bodies have more to keep: at 6 waves the per-tile kernel is 13 % slower than at 5)
-constexpr int split_waves(int features, bool count) { return (features & F_SECONDARY) ? 4 : (!count && features == F_MESH) ? 5 : render_waves(features, count); }
+constexpr int split_waves(int features, bool count) { return (features & F_SECONDARY) ? 4 : render_waves(features, count); }
 constexpr int kVariantQueue = 4;     // k_render_queue
 constexpr int kWavesPerBlock = kBlock / 64;
 constexpr int kStackWords = 3 * kStackDepth;
