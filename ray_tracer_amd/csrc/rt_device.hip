@@ -1126,7 +1126,7 @@ extern "C" int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *sc) {
     S.objects = d_objects; S.spheres = d_spheres; S.planes = d_planes; S.cones = d_cones; S.meshes = ctx->d_meshes;
     S.tri_test = ctx->d_tri_test; S.tri_key = ctx->d_tri_key; S.tri_orig = ctx->d_tri_orig;
     S.tri_nrm = d_nrm; S.tri_uv = d_uv; S.tri_material = d_tmat; S.tri_frag = ctx->d_tri_frag; S.tri_sub = ctx->d_tri_sub;
-    S.gate_tri = d_gate; S.light_cull = d_cull; S.cullable_lights = cullable; S.pad1 = 0; S.nodes = ctx->d_nodes; S.materials = d_materials; S.textures = d_tex; S.srgb_lut = d_lut;
+    S.gate_tri = d_gate; S.light_cull = d_cull; S.cullable_lights = cullable; S.gate_entry_first = (scene_features(sc) & F_SECONDARY) ? 1 : 0; S.nodes = ctx->d_nodes; S.materials = d_materials; S.textures = d_tex; S.srgb_lut = d_lut;
     S.light_pos = d_lp; S.light_color = d_lc;
     for (int a = 0; a < 3; a++) S.ambient[a] = sc->ambient[a];
     RT_HIP(hipStreamSynchronize(ctx->stream));  // the caller's arrays may go away after return
@@ -1210,6 +1210,7 @@ extern "C" int rt_scene_update(rt_ctx *ctx, const rt_scene_desc *sc) {
     for (int a = 0; a < 3; a++) S.ambient[a] = sc->ambient[a];
     RT_HIP(hipStreamSynchronize(ctx->stream));  // the caller's arrays may go away after return
     ctx->features = scene_features(sc);
+    S.gate_entry_first = (ctx->features & F_SECONDARY) ? 1 : 0;
     return RT_OK;
 }
 

@@ -195,7 +195,7 @@ void *twin_create(const rt_scene_desc *sc, char *errbuf, int errcap) {
     S.tri_frag = t->tri_frag.data(); S.tri_sub = t->tri_sub.data(); S.gate_tri = t->gate.data(); S.nodes = t->nodes.data();
     S.cullable_lights = make_light_cull(sc, t->meshes, t->axis_planes, t->gen_planes, t->light_cull);
     S.light_cull = t->light_cull.data();
-    S.srgb_lut = t->srgb_lut.data(); S.pad1 = 0;
+    S.srgb_lut = t->srgb_lut.data(); S.gate_entry_first = (scene_features(sc) & F_SECONDARY) ? 1 : 0;
     S.materials = t->materials.data(); S.textures = t->textures.data();
     S.light_pos = t->light_pos.data(); S.light_color = t->light_color.data();
     for (int a = 0; a < 3; a++) S.ambient[a] = sc->ambient[a];
