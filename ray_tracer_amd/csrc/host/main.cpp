@@ -2,17 +2,22 @@
 // builds a scene, renders it and writes an ASCII PPM; the scene, size and sampling are selectable:
 //   rt_main [out.ppm] [--preset shells|analytic|teapot|teapot_head|textured] [--size WxH]
 //           [--mode 1spp|aa9|gridN] [--depth D] [--assets DIR] [--brute] [--p6] [--device N]
-//           [--frames N [--spin DEGREES]]
+//           [--frames N [--spin DEGREES]] [--gpus N | --devices a,b,...]
 // Defaults reproduce the reference: preset shells, 1024x768, 1 spp, ./result.ppm.  An output name ending
 // in .png is written as an 8-bit RGB PNG.
 // --frames N renders N frames, turning every mesh by DEGREES (default 360 / N) about its own y axis
 // per frame, and writes out_0000.ppm ...; the geometry is uploaded and its LBVHs are built once.
+// --gpus N (devices 0 .. N-1) or --devices a,b,... renders every frame on several GPUs from this one process: a context
+// and a host thread per device, each rendering its rank's tiles (rt_render_params.rank / world_size) into a buffer of
+// its own; the buffers are merged on the host.  No collective is involved; bench.py's pipeline is the fast path.
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
+#include <memory>
 #include <stdexcept>
+#include <thread>
 
 #include "scene.hpp"
 
@@ -24,6 +29,7 @@ int main(int argc, const char *argv[]) {
     bool p6 = false;
     int frames = 1;
     float spin = 0;
+    std::vector<int> devices;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
         auto next = [&]() -> const char * { return i + 1 < argc ? argv[++i] : ""; };
@@ -38,6 +44,11 @@ int main(int argc, const char *argv[]) {
             else { std::cerr << "bad --mode\n"; return 2; }
         } else if (a == "--depth") depth = std::atoi(next());
         else if (a == "--device") device = std::atoi(next());
+        else if (a == "--gpus") { int n = std::atoi(next()); devices.clear(); for (int d = 0; d < n; d++) devices.push_back(d); }
+        else if (a == "--devices") {
+            devices.clear();
+            for (const char *q = next(); *q;) { devices.push_back(std::atoi(q)); while (*q && *q != ',') q++; if (*q == ',') q++; }
+        }
         else if (a == "--brute") accel = RT_ACCEL_BRUTE;
         else if (a == "--p6") p6 = true;
         else if (a == "--frames") frames = std::atoi(next());
@@ -51,8 +62,13 @@ int main(int argc, const char *argv[]) {
         PresetHolder holder;
         std::string err;
         if (!build_preset(preset, assets, holder, err)) throw std::runtime_error(err);
-        Renderer renderer(device);
-        renderer.upload(holder.scene);
+        if (devices.empty()) devices.push_back(device);
+        const int world = (int)devices.size();
+        std::vector<std::unique_ptr<Renderer>> renderers;
+        for (int d : devices) {
+            renderers.emplace_back(new Renderer(d));
+            renderers.back()->upload(holder.scene);
+        }
         std::cout << "Coloring each pixel on the screen..." << std::endl;
         rt_render_params p{};
         p.width = width; p.height = height; p.fov = 90; p.mode = mode; p.grid_m = grid; p.max_depth = depth;
@@ -74,14 +90,42 @@ int main(int argc, const char *argv[]) {
             if (f > 0) {
                 float angle = (float)(spin * f * 3.14159265358979323846 / 180.0);
                 for (size_t k = 0; k < movers.size(); k++) movers[k]->setTransformation(rotate(base[k], angle, vec3(0, 1, 0)));
-                renderer.update(holder.scene);
+                for (auto &r : renderers) r->update(holder.scene);
             }
-            renderer.render(p, nullptr, rgb8.data());
-            rt_counters c = renderer.counters();
-            unsigned long long rays_total = c.rays_primary + c.rays_shadow + c.rays_secondary, rays = rays_total - rays_before;
+            unsigned long long rays_total = 0;
+            float trace_ms = 0, build_ms = 0;
+            if (world == 1) {
+                renderers[0]->render(p, nullptr, rgb8.data());
+            } else {
+                // every rank's tiles into a zeroed buffer of its own (rt_render leaves the other ranks' pixels as they are), then merged
+                std::vector<std::vector<uint8_t>> part(world, std::vector<uint8_t>(rgb8.size(), 0));
+                std::vector<std::string> errors(world);
+                std::vector<std::thread> threads;
+                for (int r = 0; r < world; r++)
+                    threads.emplace_back([&, r]() {
+                        try {
+                            rt_render_params pr = p;
+                            pr.rank = r; pr.world_size = world;
+                            renderers[r]->render(pr, nullptr, part[r].data());
+                        } catch (const std::exception &e) { errors[r] = e.what(); }
+                    });
+                for (auto &t : threads) t.join();
+                for (int r = 0; r < world; r++) if (!errors[r].empty()) throw std::runtime_error("device " + std::to_string(devices[r]) + ": " + errors[r]);
+                for (size_t q = 0; q < rgb8.size(); q++) {
+                    uint8_t v = 0;
+                    for (int r = 0; r < world; r++) v |= part[r][q];  // one rank owns the pixel, the others hold 0
+                    rgb8[q] = v;
+                }
+            }
+            for (auto &r : renderers) {
+                rt_counters c = r->counters();
+                rays_total += c.rays_primary + c.rays_shadow + c.rays_secondary;
+                trace_ms = std::max(trace_ms, c.last_trace_ms); build_ms = std::max(build_ms, c.last_build_ms);
+            }
+            unsigned long long rays = rays_total - rays_before;
             rays_before = rays_total;  // the counters accumulate over frames
-            std::cout << "frame " << f << ": trace kernel " << c.last_trace_ms << " ms, " << rays << " rays, " << rays / (c.last_trace_ms * 1e3)
-                      << " Mrays/s; LBVH build " << c.last_build_ms << " ms (once)" << std::endl;
+            std::cout << "frame " << f << ": trace kernel " << trace_ms << " ms" << (world > 1 ? " (slowest of " + std::to_string(world) + " devices)" : std::string()) << ", " << rays
+                      << " rays, " << rays / (trace_ms * 1e3) << " Mrays/s; LBVH build " << build_ms << " ms (once)" << std::endl;
             std::string path = out;
             if (frames > 1) {
                 char tag[16];

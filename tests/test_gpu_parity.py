@@ -582,3 +582,12 @@ def test_command_line_driver_writes_the_same_frame(gpu_ctx, tmp_path):
     assert r.returncode == 0, r.stderr
     frames = [(tmp_path / f"turn_{k:04d}.ppm").read_bytes() for k in range(3)]
     assert all(f.startswith(b"P6") for f in frames) and len(set(frames)) == 3
+    # several devices from one process (here the same GPU three times: a context and a host thread each): the same bytes
+    multi = tmp_path / "multi.ppm"
+    r = subprocess.run([exe, str(multi), "--preset", "teapot", "--size", "96x64", "--mode", "grid2", "--devices", "0,0,0", "--assets", rt.ASSETS],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert multi.read_bytes() == out.read_bytes() and "slowest of 3 devices" in r.stdout
+    r = subprocess.run([exe, str(multi), "--preset", "teapot", "--size", "96x64", "--gpus", "64", "--assets", rt.ASSETS],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1 and "error" in r.stderr  # a device that does not exist: a message, not a crash
