@@ -6,5 +6,5 @@ for lib in "$@"; do
 import sys, json
 j = json.loads(sys.stdin.readline())
 c = j['roofline']['counts_per_launch']
-print('$lib', 'tex(node steps) M', None, 'kernel_ms %.3f' % j['roofline']['kernel_ms'], {k: round(v / 1e6, 1) for k, v in c.items()}, 'shadow queries M', j['rays']['shadow_queries_executed_per_frame'] / 1e6)" || exit 1
+print('$lib', 'kernel_ms %.3f' % j['roofline']['kernel_ms'], {k: round(v / 1e6, 1) for k, v in c.items()}, 'shadow queries M', j['rays']['shadow_queries_executed_per_frame'] / 1e6)" || exit 1
 done
