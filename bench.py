@@ -140,8 +140,8 @@ def stub_main(args, world, rank):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="teapot_4k_16spp", choices=sorted(WORKLOADS))
     ap.add_argument("--accel", default="lbvh", choices=["lbvh", "brute"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
