@@ -226,7 +226,8 @@ def main():
     # every rank's figures on rank 0: [elapsed, kernel ms, rays, shadow queries run, flops of a launch, counts...]
     mine = torch.tensor([elapsed, kernel_ms, float(c.rays), float(c.shadow_queries), float(flops_local)] +
                         [float(getattr(cw, n)) for n in count_names] +
-                        [float(cw.rays), float(cw.gate_tests), float(c.rays - c.rays_shadow + c.shadow_queries)],
+                        [float(cw.rays), float(cw.gate_tests), float(c.rays - c.rays_shadow + c.shadow_queries),
+                         float(cw.node_steps), float(cw.node_lane_visits)],
                         dtype=torch.float64, device=dev)
     rows = [torch.zeros_like(mine) for _ in range(world)]
     if world > 1:
@@ -246,6 +247,9 @@ def main():
         counts = {n: int(rows[:, 5 + i].sum()) for i, n in enumerate(count_names)}
         counts["rays"] = int(rows[:, 5 + len(count_names)].sum())
         counts["gates"] = int(rows[:, 6 + len(count_names)].sum())
+        # the packet walk: node visits per wave of 64 rays, and how many of the 64 rays took part in a visit on average
+        counts["node_steps_waves"] = int(rows[:, 8 + len(count_names)].sum())
+        node_lane_visits = float(rows[:, 9 + len(count_names)].sum())
         kernel_ms_max = float(rows[:, 1].max())
         traffic = pmc_flops = None
         pmc_path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
@@ -281,6 +285,7 @@ def main():
                          "kernel_ms_per_rank": [float(x) for x in rows[:, 1]],
                          "achieved_per_rank": per_rank_tflops,
                          "flops_per_unit": FLOPS, "counts_per_launch": counts,
+                         "packet_fill": (node_lane_visits / (64.0 * counts["node_steps_waves"])) if counts["node_steps_waves"] else None,
                          "tri_tests_per_s": (counts["tri_tests"] + counts["gate_tri_tests"]) / (kernel_ms_max * 1e-3) if kernel_ms_max > 0 else 0.0},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -193,6 +193,8 @@ typedef struct {
     uint64_t plane_tests;
     uint64_t shade_evals; /* (hit, light) Phong evaluations                        */
     uint64_t tex_fetches;
+    uint64_t node_steps;       /* tree nodes visited by the packet walk, counted once per wave of 64 rays      */
+    uint64_t node_lane_visits; /* rays that took part in those visits: / (64 * node_steps) = how full the packets are */
     float last_trace_ms;  /* device time of the last trace kernel (HIP events)     */
     float last_build_ms;  /* device time of the last rt_build_accel                */
     int32_t bvh_max_depth;

@@ -108,6 +108,7 @@ class Counters(C.Structure):
                 ("tri_tests", C.c_uint64), ("box_tests", C.c_uint64),
                 ("gate_tests", C.c_uint64), ("gate_tri_tests", C.c_uint64), ("quadric_tests", C.c_uint64),
                 ("plane_tests", C.c_uint64), ("shade_evals", C.c_uint64), ("tex_fetches", C.c_uint64),
+                ("node_steps", C.c_uint64), ("node_lane_visits", C.c_uint64),
                 ("last_trace_ms", C.c_float), ("last_build_ms", C.c_float),
                 ("bvh_max_depth", C.c_int32), ("render_variant", C.c_int32)]
 

@@ -295,10 +295,12 @@ struct DevScene {
 struct Work {
     uint32_t rays_primary, rays_shadow, rays_secondary, shadow_q;
     uint32_t tri, box, gate, gate_tri, quadric, plane, shade, tex;
+    uint32_t node_steps, node_lanes;  // packet walk: node visits counted once per wave, and the lanes that took part in them
 };
 RT_HD void work_zero(Work &w) {
     w.rays_primary = w.rays_shadow = w.rays_secondary = w.shadow_q = 0;
     w.tri = w.box = w.gate = w.gate_tri = w.quadric = w.plane = w.shade = w.tex = 0;
+    w.node_steps = w.node_lanes = 0;
 }
 
 // ---------------------------------------------------------------- textures
@@ -664,7 +666,8 @@ RT_HD void bvh_walk(const BvhNode *nodes, const f4 *tt, const uint32_t *keys, in
             u32x16 nd = load_u32x16(reinterpret_cast<const char *>(nodes) + ((uint32_t)cur << 6));
             pin_scalar(nd);
             const bool in = wave_mask_bit(inm);
-            if (COUNT && in) wk.box += 2;
+            if (COUNT && in) { wk.box += 2; wk.node_lanes++; }
+            if (COUNT && wave_uniform(wave_lane()) == wave_lane()) wk.node_steps++;  // (one lane of the wave counts the visit)
             // a lane that is not in the visit gets an empty interval: its tests below fail by themselves
             float tm = in ? best.t : -1.0f;
             uint64_t b0, b1;

@@ -29,7 +29,7 @@ using namespace rtc;
 namespace {
 
 constexpr int kBlock = 256;
-constexpr int kNumCounters = 12, kNumRayCounters = 4;  // the ray counters are kept by every kernel variant
+constexpr int kNumCounters = 14, kNumRayCounters = 4;  // the ray counters are kept by every kernel variant
 // The counters are kept in kCounterStripes copies, one 128-byte line each; a wave adds to the copy
 // its block and wave number select, and the host adds the copies up.  Hundreds of thousands of waves
 // adding to one address serialise in the L2's atomic unit (measured: 10 % of a 4 ms frame).
@@ -86,7 +86,7 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
 
 __device__ __forceinline__ void flush_work(const Work &wk, unsigned long long *counters, bool count) {
     unsigned long long vals[kNumCounters] = {wk.rays_primary, wk.rays_shadow, wk.rays_secondary, wk.shadow_q, wk.tri, wk.box,
-                                             wk.gate, wk.gate_tri, wk.quadric, wk.plane, wk.shade, wk.tex};
+                                             wk.gate, wk.gate_tri, wk.quadric, wk.plane, wk.shade, wk.tex, wk.node_steps, wk.node_lanes};
     int n = count ? kNumCounters : kNumRayCounters;
     unsigned long long *mine = counters + (size_t)((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) % kCounterStripes) * kCounterStride;
     for (int i = 0; i < n; i++) {
@@ -1737,7 +1737,7 @@ extern "C" int rt_get_counters(rt_ctx *ctx, rt_counters *out) {
     std::memset(out, 0, sizeof *out);
     out->rays_primary = c[0]; out->rays_shadow = c[1]; out->rays_secondary = c[2]; out->shadow_queries = c[3];
     out->tri_tests = c[4]; out->box_tests = c[5]; out->gate_tests = c[6]; out->gate_tri_tests = c[7]; out->quadric_tests = c[8];
-    out->plane_tests = c[9]; out->shade_evals = c[10]; out->tex_fetches = c[11];
+    out->plane_tests = c[9]; out->shade_evals = c[10]; out->tex_fetches = c[11]; out->node_steps = c[12]; out->node_lane_visits = c[13];
     float ms = 0;
     if (ctx->trace_timed && hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) == hipSuccess) ctx->last_trace_ms = ms;
     out->last_trace_ms = ctx->last_trace_ms;

@@ -591,3 +591,14 @@ def test_command_line_driver_writes_the_same_frame(gpu_ctx, tmp_path):
     r = subprocess.run([exe, str(multi), "--preset", "teapot", "--size", "96x64", "--gpus", "64", "--assets", rt.ASSETS],
                        capture_output=True, text=True, timeout=120)
     assert r.returncode == 1 and "error" in r.stderr  # a device that does not exist: a message, not a crash
+
+
+def test_packet_walk_counters(gpu_ctx):
+    """The counting kernel reports the packet walk's node visits once per wave and the rays that took part: between one
+    ray and all 64 per visit, and as many lane visits as half the slab tests made inside the walk at most."""
+    ctx = gpu_ctx("teapot")
+    ctx.reset_counters()
+    ctx.render(256, 192, want_rgb=False, mode=rt.MODE_GRID, grid_m=2, count_work=True)
+    c = ctx.counters()
+    assert c.node_steps > 0 and c.node_steps <= c.node_lane_visits <= 64 * c.node_steps
+    assert 2 * c.node_lane_visits <= c.box_tests
