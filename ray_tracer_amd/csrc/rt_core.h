@@ -25,6 +25,12 @@
 #define RT_HD inline
 #endif
 
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RT_AS4 __attribute__((address_space(4)))
+#else
+#define RT_AS4
+#endif
+
 namespace rtc {
 
 constexpr float kEps = 0.0001f;     // EPS, main.cpp:23
@@ -96,6 +102,25 @@ RT_HD int32_t wave_uniform(int32_t v) {  // the value of the first active lane, 
     return v;
 #endif
 }
+// A copy of a wave-uniform value that the optimiser cannot trace back to it.  A lane that finds `mine == u` for a
+// uniform u = wave_uniform(mine) must go on using u (a scalar register: addresses formed from it give scalar loads);
+// an optimiser that knows the two are equal there is free to substitute the per-lane value.  Comparing with
+// uniform_alias(u) instead keeps u itself out of the equality.
+RT_HD int32_t uniform_alias(int32_t u) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("" : "+s"(u));
+#endif
+    return u;
+}
+// the value a lane of `mask` holds (the lowest one), as a scalar; mask != 0
+RT_HD int32_t wave_value_at(int32_t v, uint64_t mask) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_readlane(v, __builtin_ctzll(mask));
+#else
+    (void)mask;
+    return v;
+#endif
+}
 RT_HD int wave_lane() {
 #if defined(__HIP_DEVICE_COMPILE__)
     return (int)__lane_id();
@@ -163,6 +188,9 @@ RT_HD v3 m3_mul(v3 c0, v3 c1, v3 c2, v3 v) {
     return V3(c0.x * v.x + c1.x * v.y + c2.x * v.z, c0.y * v.x + c1.y * v.y + c2.y * v.z,
               c0.z * v.x + c1.z * v.y + c2.z * v.z);
 }
+// c ? a : b by components (the conditional operator on the structs themselves selects between their ADDRESSES, and
+// the compiler then keeps both in private memory and loads through the selected address)
+RT_HD v3 select3(bool c, v3 a, v3 b) { return V3(c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z); }
 RT_HD float clamp01(float x) { float m = (x < 0.0f) ? 0.0f : x; return (1.0f < m) ? 1.0f : m; }
 
 // ---------------------------------------------------------------- device-side scene
@@ -185,6 +213,15 @@ constexpr int kOctants = 8;
 // all cones needs no shadow query at all.
 constexpr int kCullMeshes = 4;
 struct alignas(64) LightCull { f4 cone[kCullMeshes]; };
+// Everything the light loop reads of one light, 128 bytes: two scalar loads at a known place (Light, main.cpp:553-559,
+// plus the cones of its LightCull).
+struct alignas(64) LightRec {
+    float pos[3], pad0;
+    float color[3], pad1;
+    uint32_t pad2[8];
+    LightCull cull;
+};
+static_assert(sizeof(LightRec) == 128, "LightRec layout");
 constexpr uint32_t kUnusedCone = 0x40000000u;  // cos = 2.0f: the slot of a mesh that is not there
 struct BvhNode {
     float lo0[3], hi0[3];
@@ -215,28 +252,55 @@ struct alignas(64) DevMesh : MeshHead {
 };
 static_assert(sizeof(MeshHead) == 64 && sizeof(DevMesh) == 320, "DevMesh layout");
 
-// What the plane tests of find_closest read.  Planes whose normal is exactly +-e_a (the walls of a
-// room) take 16 bytes, so that four of them arrive with one 64-byte scalar load; the others take 32
-// bytes and arrive two at a time.  Both arrays are padded with inert records (axis / object 0 / -1)
-// to a multiple of the group size.
+// What the plane pass of find_closest reads.  Planes whose normal is exactly +-e_a (the walls of a room) are kept as
+// pairs: the plane with normal +e_a and the one with normal -e_a of one axis a, 32 bytes, either of them possibly
+// absent.  Pairs 0, 1, 2 are the first such planes of the axes x, y, z (tested with the ray component known at compile
+// time); further planes of an axis follow as overflow pairs.  The array is padded to whole 64-byte loads.  All other
+// planes take 32 bytes each and arrive two per load.
 // cannot_shadow: a shadow ray runs from a surface point to light l and only asks whether something
 // lies closer than the light.  A plane is hit on its front face only, i.e. by a ray that passes from
 // its front side to its back side; when the light is on the front side (by a margin far above
 // rounding) the crossing lies beyond the light, so the plane cannot change the answer and the test is
 // skipped for that light's shadow rays.  In a room lit from inside this removes every wall from
 // every shadow ray.
-struct AxisPlaneRec {
-    int32_t axis;    // +-(a+1): the normal is +-e_a; 0: padding
-    float coord;     // point[a]
-    int32_t object;  // index in the object list
-    uint32_t cannot_shadow;  // bit l: the plane can never lie between a surface point and light l (l < 32)
+struct AxisPair {
+    float coord_pos;     // point[a] of the plane with normal +e_a
+    int32_t object_pos;  // its index in the object list, -1: no such plane
+    uint32_t cs_pos;     // bit l: the plane can never lie between a surface point and light l (l < 32)
+    float coord_neg;     // the same for the plane with normal -e_a
+    int32_t object_neg;
+    uint32_t cs_neg;
+    int32_t axis;        // a
+    uint32_t pad;
 };
 struct PlaneRec {
     float n[3], p[3];
     int32_t object;  // index in the object list, -1: padding
     uint32_t cannot_shadow;
 };
-constexpr int kAxisPlaneGroup = 4, kPlaneGroup = 2;
+constexpr int kAxisPairGroup = 2, kPlaneGroup = 2, kFixedAxisPairs = 4;  // (pairs 0-2 and an empty one: two loads; overflow pairs after them)
+
+// What shading needs of a material, 64 bytes: one scalar load when all lanes shade the same material.
+struct MatRec {
+    float ambient[3];  // ambient_light * material.ambient: the colour PhongModel starts from (main.cpp:646)
+    float diffuse[3], specular[3];
+    float shininess, reflectiveness, refractiveness, refractive_ratio;
+    uint32_t tex_wh;          // image texture: width | height << 16
+    uint32_t tex_lo, tex_hi;  // image texture: the address of its texel records (16-byte aligned); the low 4 bits of
+                              // tex_lo say what the texture is: 0 none, 1 + RT_TEX_* otherwise
+};
+// What turning a closest hit into a shaded surface needs of an object, 128 bytes (two scalar loads when all lanes
+// resolve the same object): the geometry that is not in the tables of the object's kind, and the material.
+struct alignas(64) ObjRec {
+    int32_t kind, index;  // rt_object
+    int32_t material;     // index of `mat` in the material table; -1: a mesh whose triangles have materials of their own
+    uint32_t pad0;
+    float n[3];           // plane: the normal as given (main.cpp:212-218)
+    float nn[3];          // plane: normalize(n), what Plane::intersect reports without a normal map (main.cpp:250)
+    float b1[3], b2[3];   // plane: texture base vectors (main.cpp:207-210)
+    MatRec mat;
+};
+static_assert(sizeof(MatRec) == 64 && sizeof(ObjRec) == 128 && sizeof(AxisPair) == 32, "record layout");
 
 struct DevTexture {
     int32_t kind;
@@ -260,36 +324,94 @@ struct SphereCull {
     int32_t object;
 };
 
-struct DevScene {
-    int32_t n_objects, n_lights;
-    int32_t n_planes, n_spheres, n_cones, n_meshes;
-    const rt_object *objects;
-    const int32_t *plane_obj, *cone_obj;  // index of each plane / cone in `objects` (meshes: MeshHead::object)
+// The scene record.  It lives in device memory and the kernels read it through scalar loads, so the small tables
+// that every sample needs are part of the record itself (one load at a known offset, no pointer to fetch first):
+// the axis-plane pairs, and the first few general planes, mesh heads, object records and lights.  Entries beyond
+// those capacities are read through the pointers next to them.  Fields are grouped by the phase that reads them.
+constexpr int kEmbGenPlanes = 4, kEmbMeshes = 4, kEmbObjects = 8, kEmbLights = 8;
+struct alignas(64) DevScene {
+    // ---- closest-hit query
+    uint32_t planes_skip_lights;  // bit l: no plane can shadow light l, its shadow rays skip the plane pass (l < 32)
+    int32_t n_axis_overflow, n_gen_planes;  // overflow pairs / general planes, both padded to whole loads
+    int32_t n_meshes, n_spheres, n_cones, n_planes, n_objects;
+    const AxisPair *axis_overflow;  // pairs beyond the fixed ones
+    const PlaneRec *gen_planes;     // all general planes (the first kEmbGenPlanes also in gen_first)
+    const DevMesh *meshes;          // all meshes (the heads of the first kEmbMeshes also in mesh_heads)
     const SphereCull *sphere_cull;
-    int32_t n_axis_planes, n_gen_planes;  // padded counts
-    const AxisPlaneRec *axis_planes;
-    const PlaneRec *gen_planes;
+    AxisPair axis_pairs[kFixedAxisPairs];
+    PlaneRec gen_first[kEmbGenPlanes];
+    MeshHead mesh_heads[kEmbMeshes];
     const rt_sphere *spheres;
-    const rt_plane *planes;
     const rt_cone *cones;
-    const DevMesh *meshes;
+    const int32_t *plane_obj, *cone_obj;  // index of each plane / cone in `objects` (meshes: MeshHead::object)
+    const rt_plane *planes;
+    // ---- tree walk and Box gate
+    const BvhNode *nodes;
     const f4 *tri_test;        // 3 x f4 per sorted triangle: p1 p2 p3 sn
     const uint32_t *tri_key;   // per sorted triangle: 2*frag + (1 - sub), the tie-break order
+    const f4 *gate_tri;        // 3 x f4 per Box triangle, 12 per mesh
+    int32_t gate_entry_first;  // the scene has secondary rays: its kernels test the Box gate's entry face first (mesh_geom); read by the counting kernel only
+    int32_t pad0;
+    // ---- from a closest hit to a shading context
+    const ObjRec *obj_recs;       // per object (the first kEmbObjects also in obj_first)
+    const MatRec *mat_recs;       // per material
     const int32_t *tri_orig;   // sorted position -> index into the arrays below
     const float *tri_nrm;      // [n][9]
     const float *tri_uv;       // [n][6]
     const int32_t *tri_material, *tri_frag, *tri_sub;
-    const f4 *gate_tri;        // 3 x f4 per Box triangle, 12 per mesh
-    const LightCull *light_cull;  // per light
-    uint32_t cullable_lights;     // bit l: light_cull[l] decides alone whether a shadow query is needed (l < 32)
-    int32_t gate_entry_first;  // the scene has secondary rays: its kernels test the Box gate's entry face first (mesh_geom); read by the counting kernel only
-    const BvhNode *nodes;
+    const float *srgb_lut;     // [256] pow(b / 255, 2.2): the base-colour decoding of Textures.cpp:41-43 per byte value
+    const rt_object *objects;      // (the entry points that report hit records)
     const rt_material *materials;
     const DevTexture *textures;
-    const float *srgb_lut;     // [256] pow(b / 255, 2.2): the base-colour decoding of Textures.cpp:41-43 per byte value
-    const float *light_pos, *light_color;
-    float ambient[3];
+    ObjRec obj_first[kEmbObjects];
+    // ---- lights
+    int32_t n_lights;
+    uint32_t cullable_lights;       // bit l: the cones of light l decide alone whether a shadow query is needed (l < 32)
+    const LightRec *light_recs;     // all lights (the first kEmbLights also in light_first)
+    uint32_t pad1[12];
+    LightRec light_first[kEmbLights];
 };
+// How the per-ray code sees the scene: a reference to the record in device memory, read through the constant
+// address space (always scalar loads).  The kernels receive its address, two scalar registers, instead of the
+// record itself: sixty-odd kernel-argument registers that stayed live through every loop pushed as many other
+// scalar values into vector-register lanes.  fresh() hands out the same reference in a form the optimiser cannot
+// connect with earlier uses: what a phase (a closest-hit query, the resolution of a hit, one light) reads of the
+// record is fetched when the phase starts and occupies registers only while the phase runs.  `with`: a value of
+// the phase's own (its ray, its hit): the reference counts as computed from it, so it cannot be formed before the
+// phase.  (The statement emits nothing and touches no memory: loads that follow it stay scalar loads.)
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef const DevScene RT_AS4 &SceneRef;
+RT_HD SceneRef fresh(SceneRef S, float with) {
+    const DevScene RT_AS4 *p = &S;
+    asm("" : "+s"(p) : "v"(with));
+    return *p;
+}
+RT_HD SceneRef scene_ref(const DevScene *p) { return *(const DevScene RT_AS4 *)(uintptr_t)p; }
+#else
+typedef const DevScene &SceneRef;
+RT_HD SceneRef fresh(SceneRef S, float) { return S; }
+RT_HD SceneRef scene_ref(const DevScene *p) { return *p; }
+#endif
+
+// Where record i of a table lives: in the scene record itself (an address known without a load), or behind the
+// table's pointer.  The pointer is read in the branch that needs it, through a reference of its own (fresh), so that
+// the common case never waits for it.
+RT_HD const char *gen_plane_at(SceneRef S, int32_t i, float with) {
+    if (i < kEmbGenPlanes) return (const char *)(uintptr_t)&S.gen_first[i];
+    return (const char *)(fresh(S, with).gen_planes + i);
+}
+RT_HD const char *mesh_head_at(SceneRef S, int32_t i, float with) {
+    if (i < kEmbMeshes) return (const char *)(uintptr_t)&S.mesh_heads[i];
+    return (const char *)(fresh(S, with).meshes + i);
+}
+RT_HD const char *obj_rec_at(SceneRef S, int32_t i, float with) {
+    if (i < kEmbObjects) return (const char *)(uintptr_t)&S.obj_first[i];
+    return (const char *)(fresh(S, with).obj_recs + i);
+}
+RT_HD const char *light_rec_at(SceneRef S, int32_t i, float with) {
+    if (i < kEmbLights) return (const char *)(uintptr_t)&S.light_first[i];
+    return (const char *)(fresh(S, with).light_recs + i);
+}
 
 // per-thread work counters; the counting variant is a separate template instantiation
 struct Work {
@@ -305,10 +427,13 @@ RT_HD void work_zero(Work &w) {
 
 // ---------------------------------------------------------------- textures
 
-// ImageTexture::getRGBAat, Textures.cpp:27-35.  `int % unsigned` is unsigned arithmetic.
-// ImageTexture::getRGBAat (Textures.cpp:26-39) for all four maps at once: the texel record at uv
+// An image texture as the samplers need it: size and texel records (wave-uniform values when they come from a
+// MatRec that was fetched for the whole wave, per-lane values otherwise).
+struct TexRef { uint32_t w, h; const u4 *texels; };
+// ImageTexture::getRGBAat (Textures.cpp:26-39) for all four maps at once: the texel record at uv.
+// `int % unsigned` is unsigned arithmetic.
 template <bool COUNT>
-RT_HD u4 tex_texel(const DevTexture &t, v2 uv, Work &wk) {
+RT_HD u4 tex_texel(TexRef t, v2 uv, Work &wk) {
     if (COUNT) wk.tex++;
     float fx = 2 * uv.x * (float)t.w;
     float fy = 2 * uv.y * (float)t.h;
@@ -331,28 +456,42 @@ RT_HD v3 tex_procedural(int kind, v2 uv) {
         return V3((float)v, (float)v, (float)v);
     }
     int v = (int)floorf(18 * (uv.x + uv.y)) % 3;
-    return v == 0 ? V3(1, 0, 0) : v == 1 ? V3(0, 1, 0) : v == 2 ? V3(0, 0, 1) : V3(0, 0, 0);
+    return V3(v == 0 ? 1.0f : 0.0f, v == 1 ? 1.0f : 0.0f, v == 2 ? 1.0f : 0.0f);
 }
 // ImageTexture::texture (Textures.cpp:41-43): pow(channel, 2.2) of the base colour, from the table
-RT_HD v3 tex_base_color(const DevScene &S, uint32_t px) {
+RT_HD v3 tex_base_color(SceneRef S, uint32_t px) {
     return V3(S.srgb_lut[px & 255u], S.srgb_lut[(px >> 8) & 255u], S.srgb_lut[(px >> 16) & 255u]);
 }
-RT_HD const DevTexture *image_texture_of(const DevScene &S, const rt_material &m) {
+RT_HD const DevTexture *image_texture_of(SceneRef S, const rt_material &m) {
     if (m.texture < 0) return nullptr;
     const DevTexture *t = &S.textures[m.texture];
     return t->kind == RT_TEX_IMAGE ? t : nullptr;
 }
+RT_HD TexRef tex_ref(const DevTexture &t) { TexRef r; r.w = t.w; r.h = t.h; r.texels = t.texels; return r; }
+// what a MatRec says about its texture
+RT_HD int mat_tex_kind(uint32_t tex_lo) { return (int)(tex_lo & 15u) - 1; }  // -1: none, else RT_TEX_*
+RT_HD TexRef mat_tex_ref(uint32_t tex_wh, uint32_t tex_lo, uint32_t tex_hi) {
+    TexRef r;
+    r.w = tex_wh & 0xffffu; r.h = tex_wh >> 16;
+    r.texels = reinterpret_cast<const u4 *>((uintptr_t)(((uint64_t)tex_hi << 32) | (uint64_t)(tex_lo & ~15u)));
+    return r;
+}
 
 // ---------------------------------------------------------------- analytic primitives
 
-struct Surf {  // a resolved hit (Hit, main.cpp:45-53)
-    u4 texel;         // the texture record at uv, when the surface function fetched it
-    bool has_texel;
+// A resolved hit without its material (Hit's point, normal, uv and from_outside, main.cpp:45-53) plus the
+// texture record the surface function read on the way (normal-mapped surfaces), so that shading need not read
+// it again.  Plain scalars only: the struct lives in registers.
+struct SurfGeo {
     v3 point, normal;
     v2 uv;
+    uint32_t tex_color, tex_normal, tex_occlusion, tex_roughness;  // the four RGBA8 texels at uv, when has_texel
+    bool has_texel, from_outside;
+};
+RT_HD void geo_set_texel(SurfGeo &g, u4 t) { g.tex_color = t.x; g.tex_normal = t.y; g.tex_occlusion = t.z; g.tex_roughness = t.w; g.has_texel = true; }
+struct Surf : SurfGeo {  // a resolved hit as the hit records report it
     int32_t material;
     int32_t frag, sub;
-    bool from_outside;
 };
 
 // Plane::intersect, main.cpp:222-257.  Returns the ray parameter (the plane's `distance`).
@@ -363,26 +502,23 @@ RT_HD bool plane_hit(const rt_plane &pl, v3 ro, v3 rd, float &t) {
     t = PdotN / DdotN;  // evaluated unconditionally (no divergent exit); only used when DdotN < 0
     return (DdotN < 0) & (t > 0);
 }
-template <int F, bool COUNT>
-RT_HD void plane_surface(const DevScene &S, const rt_plane &pl, v3 ro, v3 rd, float t, Surf &s, Work &wk) {
-    v3 n = ld3(pl.normal), b1 = ld3(pl.b1), b2 = ld3(pl.b2);
+// Plane::intersect, main.cpp:231-250: point, uv and normal of a hit at ray parameter t.  n: the plane's normal as
+// given, nn: normalize(n) (what the plane reports unless its material has an image texture: then the normal map's
+// texel is carried into the basis (b1, b2, n), main.cpp:241-249).
+template <bool COUNT>
+RT_HD void plane_geo(v3 n, v3 nn, v3 b1, v3 b2, bool image, TexRef tex, v3 ro, v3 rd, float t, SurfGeo &s, Work &wk) {
     s.point = rd * t + ro;
     s.uv.x = dot(b1, s.point);
     s.uv.y = dot(b2, s.point);
-    s.material = pl.material;
-    const DevTexture *it = (F & F_TEXTURE) ? image_texture_of(S, S.materials[pl.material]) : nullptr;
     s.has_texel = false;
-    if (it) {
-        s.texel = tex_texel<COUNT>(*it, s.uv, wk);
-        s.has_texel = true;
-        v3 tn = unpack_rgb8(s.texel.y);
+    s.normal = nn;
+    if (image) {
+        geo_set_texel(s, tex_texel<COUNT>(tex, s.uv, wk));
+        v3 tn = unpack_rgb8(s.tex_normal);
         tn = tn * 2.f - V3(1, 1, 1);
-        n = m3_mul(b1, b2, n, tn);
+        s.normal = normalize(m3_mul(b1, b2, n, tn));
     }
-    s.normal = normalize(n);
     s.from_outside = true;
-    s.frag = 0;
-    s.sub = 0;
 }
 
 struct QuadricHit {
@@ -434,22 +570,19 @@ RT_HD bool sphere_geom(const rt_sphere &sp, v3 ro, v3 rd, QuadricHit &q) {
     return true;
 }
 // Sphere::intersect, main.cpp:153-181 (uv, normal mapping, world transform)
-template <int F, bool COUNT>
-RT_HD void sphere_surface(const DevScene &S, const rt_sphere &sp, const QuadricHit &q, Surf &s, Work &wk) {
+template <bool COUNT>
+RT_HD void sphere_geo(const rt_sphere &sp, const QuadricHit &q, bool image, TexRef tex, SurfGeo &s, Work &wk) {
     v3 i = q.i;
     s.uv.x = (float)(((double)atan2f(i.z, i.x) + kPi) / kPi);
     s.uv.y = (float)(((double)asinf(i.y) + kPi / 2) / kPi);
     s.point = xform_point(sp.to_world, i);
-    s.material = sp.material;
-    const DevTexture *it = (F & F_TEXTURE) ? image_texture_of(S, S.materials[sp.material]) : nullptr;
     v3 n;
     s.has_texel = false;
-    if (it) {
+    if (image) {
         v3 tangent = V3(sinf(s.uv.x), 0, cosf(s.uv.x));
         v3 bitangent = cross(i, tangent);
-        s.texel = tex_texel<COUNT>(*it, s.uv, wk);
-        s.has_texel = true;
-        v3 tn = unpack_rgb8(s.texel.y);
+        geo_set_texel(s, tex_texel<COUNT>(tex, s.uv, wk));
+        v3 tn = unpack_rgb8(s.tex_normal);
         tn = tn * 2.f - V3(1, 1, 1);
         tn = m3_mul(normalize(tangent), normalize(bitangent), normalize(i), tn);
         n = xform_dir(sp.normal_mat, tn);
@@ -458,8 +591,6 @@ RT_HD void sphere_surface(const DevScene &S, const rt_sphere &sp, const QuadricH
     }
     s.normal = normalize(n);
     s.from_outside = q.from_outside;
-    s.frag = 0;
-    s.sub = 0;
 }
 
 // Cone::intersect, main.cpp:269-325
@@ -494,13 +625,14 @@ RT_HD bool cone_geom(const rt_cone &cn, v3 ro, v3 rd, QuadricHit &q) {
     q.distance = distance(ro, xform_point(cn.to_world, q.i));
     return true;
 }
-template <int F, bool COUNT>
-RT_HD void cone_surface(const DevScene &S, const rt_cone &cn, const QuadricHit &q, Surf &s, Work &wk) {
-    s.has_texel = false;
+// cap_image / cap_tex: the image texture of the cap plane's material (the cap is a Plane of its own, main.cpp:261-266)
+template <bool COUNT>
+RT_HD void cone_geo(const rt_cone &cn, const QuadricHit &q, bool cap_image, TexRef cap_tex, SurfGeo &s, Work &wk) {
     v3 n;
     if (q.cap) {
-        Surf ps;
-        plane_surface<F, COUNT>(S, cn.cap, q.o, q.d, q.t, ps, wk);
+        SurfGeo ps;
+        v3 cap_n = ld3(cn.cap.normal);
+        plane_geo<COUNT>(cap_n, normalize(cap_n), ld3(cn.cap.b1), ld3(cn.cap.b2), cap_image, cap_tex, q.o, q.d, q.t, ps, wk);
         s.uv = ps.uv;
         n = ps.normal;
         s.point = ps.point;
@@ -512,12 +644,10 @@ RT_HD void cone_surface(const DevScene &S, const rt_cone &cn, const QuadricHit &
         s.uv.y = i.y;
         s.point = i;
     }
+    s.has_texel = false;  // (the cap's texel, if any, was read at the cap's own uv for the cap's own material: shading reads its own)
     s.point = xform_point(cn.to_world, s.point);
     s.normal = normalize(xform_dir(cn.normal_mat, n));
-    s.material = cn.material;
     s.from_outside = true;
-    s.frag = 0;
-    s.sub = q.cap ? 1 : 0;
 }
 
 // ---------------------------------------------------------------- triangles and meshes
@@ -565,7 +695,7 @@ RT_HD bool tri_hits(const f4 *tt, int32_t k, v3 o, v3 d) {
 }
 
 // Triangle::intersect, main.cpp:397-413: interpolated normal, uv, from_outside (local space)
-RT_HD void tri_surface(const DevScene &S, int32_t k, float t, v3 o, v3 d, v3 &p, v3 &n, v2 &uv,
+RT_HD void tri_surface(SceneRef S, int32_t k, float t, v3 o, v3 d, v3 &p, v3 &n, v2 &uv,
                        bool &from_outside, int32_t &orig) {
     const f4 *tt = S.tri_test;
     f4 A = tt[3 * k], B = tt[3 * k + 1], C = tt[3 * k + 2];
@@ -614,6 +744,8 @@ RT_HD float safe_rcp(float x) {
     return fabsf(x) >= 1e-30f ? 1.0f / x : copysignf(1e30f, x);
 #endif
 }
+
+RT_HD float safe_rcp_of(float x, float rcp_x) { return fabsf(x) >= 1e-30f ? rcp_x : copysignf(1e30f, x); }  // safe_rcp(x), given the reciprocal
 
 // The same test in fused form for the traversal loop: t = bound * inv - o * inv.  The boxes of the
 // tree are padded by ~100 ulps of the mesh's largest coordinate, far more than the rounding
@@ -712,7 +844,7 @@ RT_HD void bvh_walk(const BvhNode *nodes, const f4 *tt, const uint32_t *keys, in
 // its shadow / bounce rays) and share most of their path through the tree.
 // `want`: this lane's ray takes part.  Stack: put(slot, node, mask) / get(slot, node, mask).
 template <bool COUNT, class Stack>
-RT_HD void bvh_closest_packet(const DevScene &S, const MeshHead &m, v3 o, v3 d, bool want, TriBest &best, Stack &stk, Work &wk) {
+RT_HD void bvh_closest_packet(SceneRef S, const MeshHead &m, v3 o, v3 d, bool want, TriBest &best, Stack &stk, Work &wk) {
     const uint64_t wants = wave_ballot(want);
     if (wants == 0) return;
     const BvhNode *nodes = S.nodes + m.node_offset;
@@ -757,7 +889,7 @@ struct MeshHit {
 // first and the 12 exact triangle tests run only for rays that found a triangle (the gate is a
 // conjunct of the result, so the order does not matter).
 template <bool COUNT, bool ENTRY_FIRST, class Stack>
-RT_HD bool mesh_geom(const DevScene &S, const MeshHead &h, const DevMesh &m, v3 ro, v3 rd, v3 winv, v3 woi, bool want, int accel, float clip, MeshHit &mh, Stack &stk, Work &wk) {
+RT_HD bool mesh_geom(SceneRef S, const MeshHead &h, const DevMesh &m, v3 ro, v3 rd, v3 winv, v3 woi, bool want, int accel, float clip, MeshHit &mh, Stack &stk, Work &wk) {
     // phase 1, per lane: cheap rejections
     float tn;
     if (COUNT && want) wk.box++;
@@ -830,17 +962,14 @@ RT_HD bool mesh_geom(const DevScene &S, const MeshHead &h, const DevMesh &m, v3 
     mh.distance = distance(ro, xform_point(m.to_world, p));
     return true;
 }
-RT_HD void mesh_surface(const DevScene &S, const DevMesh &m, v3 ro, v3 rd, float t, int32_t k, Surf &s) {
+RT_HD void mesh_geo(SceneRef S, const DevMesh &m, v3 ro, v3 rd, float t, int32_t k, SurfGeo &s, int32_t &orig) {
     s.has_texel = false;
     v3 d = xform_dir(m.to_local, rd);
     v3 o = xform_point(m.to_local, ro);
-    v3 p, n; int32_t orig;
+    v3 p, n;
     tri_surface(S, k, t, o, d, p, n, s.uv, s.from_outside, orig);
     s.point = xform_point(m.to_world, p);
     s.normal = normalize(xform_dir(m.normal_mat, n));
-    s.material = S.tri_material[orig];
-    s.frag = S.tri_frag[orig];
-    s.sub = S.tri_sub[orig];
 }
 
 // ---------------------------------------------------------------- closest hit
@@ -854,6 +983,13 @@ RT_HD float shade_rcp(float x) {
     return __builtin_amdgcn_rcpf(x);
 #else
     return 1.0f / x;
+#endif
+}
+RT_HD float shade_rsq(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rsqf(x);
+#else
+    return 1.0f / sqrtf(x);
 #endif
 }
 // pow(x, y) for x in [0, 1], y >= 0 (Phong lobe, main.cpp:678)
@@ -887,43 +1023,128 @@ struct Closest {
 RT_HD bool closer(float dist, int32_t idx, const Closest &best) {
     return (dist > kMinDist) & ((dist < best.distance) | ((dist == best.distance) & (idx < best.object)));
 }
-// the common tail of both plane tests: estimate, wave-wide skip, exact quotient, acceptance
-// (`facing` and the skip test are kept as wave masks: a ballot taken directly of a comparison is the
-// comparison's own result register, while a ballot of a combined bool costs two more vector instructions)
-template <bool COUNT>
-RT_HD void plane_accept(float DdotN, float PdotN, uint64_t facing, int32_t idx, Closest &best, Work &wk) {
-    if (COUNT) wk.plane++;
-    float est = PdotN * shade_rcp(DdotN);
-    uint64_t maybe = facing & wave_ballot(est > 0.5f * kMinDist) & ~wave_ballot(est > best.distance * 1.00001f);
-    if (maybe != 0) {
-        float t = PdotN / DdotN;
-        const bool faces = wave_mask_bit(facing), ahead = t > 0, nearer = closer(t, idx, best);
-        bool ok = faces & ahead & nearer;
-        best.distance = ok ? t : best.distance; best.object = ok ? idx : best.object; best.t = ok ? t : best.t;
-    }
+// ---- planes (Plane::intersect, main.cpp:222-237)
+//
+// The reference divides PdotN by DdotN for every plane the ray faces and keeps the smallest quotient above 0.01
+// (ties: the plane that comes first in the object list).  Here one pass over the plane records forms, per lane and
+// without a branch, a 1-ulp ESTIMATE of each quotient (PdotN times the hardware reciprocal of DdotN) and keeps the
+// smallest one with its PdotN, DdotN and object, plus the second smallest estimate.  The exact quotient is then
+// formed once, for the lane's winner.  An estimate is within 2e-7 relative of its quotient, so the winner is the
+// reference's whenever the runner-up is more than 1e-5 relative behind and the 0.01 cut is not within 1e-5 relative
+// of the winner; any lane for which that cannot be said sends the whole wave through planes_exact, the reference's
+// own sequence of divisions (a ray within 1e-5 relative of an edge where two planes meet: practically never).
+struct PlaneCand {
+    float est;       // smallest estimate so far (INFINITY: none)
+    float second;    // second smallest
+    float P, D;      // PdotN and DdotN of the plane with the smallest estimate
+    int32_t object;
+};
+constexpr float kEstMin = kMinDist * (1.0f - 1e-5f);
+RT_HD float med3(float a, float b, float c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_fmed3f(a, b, c);
+#else
+    return fmaxf(fminf(a, b), fminf(fmaxf(a, b), c));
+#endif
 }
-template <bool COUNT>
-RT_HD void plane_axis_test(int32_t axis, float coord, int32_t idx, uint32_t skip, v3 ro, v3 rd, uint64_t finite, Closest &best, Work &wk) {
-    if (axis == 0 || skip != 0) return;  // padding, or a plane that cannot shadow this wave's light (wave-uniform)
-    // (-q) / (-dd) == q / dd bit for bit, so the sign of the normal only decides `facing`
-    int a = (axis < 0 ? -axis : axis) - 1;
-    float dd = a == 0 ? rd.x : a == 1 ? rd.y : rd.z;
-    float oo = a == 0 ? ro.x : a == 1 ? ro.y : ro.z;
-    uint64_t ahead = wave_ballot(dd > 0), against = wave_ballot(dd < 0);
-    plane_accept<COUNT>(dd, coord - oo, finite & (axis < 0 ? ahead : against), idx, best, wk);
+// est: NaN (or anything not above kEstMin) unless the lane's ray faces the plane and the plane lies ahead
+RT_HD void plane_candidate(PlaneCand &c, float est, float P, float D, int32_t object) {
+    float e = est > kEstMin ? est : INFINITY;
+    bool lt = e < c.est;
+    c.second = med3(c.second, e, c.est);  // (second >= est always: the median of the three is the new second smallest)
+    c.est = lt ? e : c.est; c.P = lt ? P : c.P; c.D = lt ? D : c.D; c.object = lt ? object : c.object;
 }
+// The two planes of one axis a, normals +e_a and -e_a.  A ray faces at most one of them: +e_a when its direction
+// component d_a is negative, -e_a when it is positive (with d_a == 0 neither: the estimate is then infinite or NaN),
+// so one estimate serves the pair.  For a normal +-e_a the reference's dot products reduce exactly to the a-th
+// components (x * 0 = +-0 and v + +-0 = v, finite components: the caller handles the others), and for -e_a the
+// quotient (-q) / (-d_a) equals q / d_a bit for bit: the candidate carries q and d_a themselves.
+// coord_pos / coord_neg: NaN when there is no such plane (or none that can shadow this wave's light); r_a: 1-ulp 1 / d_a.
 template <bool COUNT>
-RT_HD void plane_gen_test(const u32x16 &g, int at, uint32_t light_bit, v3 ro, v3 rd, Closest &best, Work &wk) {
+RT_HD void plane_axis_pair(float coord_pos, int32_t object_pos, float coord_neg, int32_t object_neg, float o_a, float d_a, float r_a,
+                           PlaneCand &c, Work &wk) {
+    const bool down = d_a < 0;
+    const float coord = down ? coord_pos : coord_neg;
+    const int32_t object = down ? object_pos : object_neg;
+    if (COUNT && coord == coord) wk.plane++;
+    const float q = coord - o_a;
+    plane_candidate(c, q * r_a, q, d_a, object);
+}
+// words `at` .. `at + 7` of g: an AxisPair; a plane that cannot shadow the wave's light counts as absent
+RT_HD float pair_coord(uint32_t coord, uint32_t cs, uint32_t light_bit) { return (cs & light_bit) != 0 ? NAN : u2f(coord); }
+template <bool COUNT>
+RT_HD void plane_general(const u32x16 &g, int at, uint32_t light_bit, v3 ro, v3 rd, PlaneCand &c, Work &wk) {
     int32_t idx = (int32_t)g[at + 6];
     if (idx < 0 || (g[at + 7] & light_bit) != 0) return;  // padding, or cannot shadow this wave's light (wave-uniform)
+    if (COUNT) wk.plane++;
     v3 n = V3(u2f(g[at]), u2f(g[at + 1]), u2f(g[at + 2]));
     float DdotN = dot(rd, n);
     float PdotN = dot(V3(u2f(g[at + 3]), u2f(g[at + 4]), u2f(g[at + 5])) - ro, n);
-    plane_accept<COUNT>(DdotN, PdotN, wave_ballot(DdotN < 0), idx, best, wk);
+    float est = PdotN * shade_rcp(DdotN);
+    plane_candidate(c, DdotN < 0 ? est : NAN, PdotN, DdotN, idx);
+}
+// The reference's own sequence for every listed plane (the rare waves with a lane too close to call).
+template <bool COUNT>
+RT_HD void planes_exact(SceneRef S, v3 ro, v3 rd, Closest &best, Work &wk) {
+    best.distance = INFINITY; best.object = -1; best.t = 0; best.k = 0;
+    for (int32_t i = 0; i < S.n_planes; i++) {
+        int32_t idx = S.plane_obj[i];
+        if (idx < 0) continue;
+        if (COUNT) wk.plane++;
+        float t;
+        bool ok = plane_hit(S.planes[i], ro, rd, t) && closer(t, idx, best);
+        best.distance = ok ? t : best.distance; best.object = ok ? idx : best.object; best.t = ok ? t : best.t;
+    }
+}
+// rinv: 1-ulp reciprocals of the direction's components
+template <bool COUNT>
+RT_HD void planes_pass(SceneRef S, v3 ro, v3 rd, v3 rinv, uint32_t light_bit, Closest &best, Work &wk) {
+    PlaneCand c;
+    c.est = INFINITY; c.second = INFINITY; c.P = 0; c.D = 1; c.object = -1;
+    {
+        u32x16 g0 = load_u32x16((const void *)(uintptr_t)&S.axis_pairs[0]), g1 = load_u32x16((const void *)(uintptr_t)&S.axis_pairs[2]);
+        pin_scalar(g0); pin_scalar(g1);
+        plane_axis_pair<COUNT>(pair_coord(g0[0], g0[2], light_bit), (int32_t)g0[1], pair_coord(g0[3], g0[5], light_bit), (int32_t)g0[4], ro.x, rd.x, rinv.x, c, wk);
+        plane_axis_pair<COUNT>(pair_coord(g0[8], g0[10], light_bit), (int32_t)g0[9], pair_coord(g0[11], g0[13], light_bit), (int32_t)g0[12], ro.y, rd.y, rinv.y, c, wk);
+        plane_axis_pair<COUNT>(pair_coord(g1[0], g1[2], light_bit), (int32_t)g1[1], pair_coord(g1[3], g1[5], light_bit), (int32_t)g1[4], ro.z, rd.z, rinv.z, c, wk);
+    }
+    // overflow pairs (an axis with several planes of one orientation): the axis is a wave-uniform value
+    for (int32_t i = 0; i < S.n_axis_overflow; i += 2) {
+        u32x16 g = load_u32x16(S.axis_overflow + i);
+        pin_scalar(g);
+        for (int at = 0; at < 16; at += 8) {
+            const int32_t a = (int32_t)g[at + 6];
+            float o_a = a == 0 ? ro.x : a == 1 ? ro.y : ro.z, d_a = a == 0 ? rd.x : a == 1 ? rd.y : rd.z;
+            float r_a = a == 0 ? rinv.x : a == 1 ? rinv.y : rinv.z;
+            plane_axis_pair<COUNT>(pair_coord(g[at], g[at + 2], light_bit), (int32_t)g[at + 1], pair_coord(g[at + 3], g[at + 5], light_bit),
+                                   (int32_t)g[at + 4], o_a, d_a, r_a, c, wk);
+        }
+    }
+    for (int32_t i = 0; i < S.n_gen_planes; i += kPlaneGroup) {
+        u32x16 g = load_u32x16(gen_plane_at(S, i, rd.y));
+        pin_scalar(g);
+        plane_general<COUNT>(g, 0, light_bit, ro, rd, c, wk);
+        plane_general<COUNT>(g, 8, light_bit, ro, rd, c, wk);
+    }
+    const float t = c.P / c.D;  // the reference's quotient (main.cpp:233) for the lane's winner
+    // With a non-finite component the reference's dot products with +-e_a are NaN and the plane is missed; the general
+    // planes' own dot products say so themselves.  (Judged for the lane's winner, whichever kind it is: a ray with a
+    // non-finite component misses every plane.)
+    float adx = fabsf(rd.x), ady = fabsf(rd.y), adz = fabsf(rd.z), aox = fabsf(ro.x), aoy = fabsf(ro.y), aoz = fabsf(ro.z);
+    const uint64_t finite = wave_ballot(adx < INFINITY) & wave_ballot(ady < INFINITY) & wave_ballot(adz < INFINITY) &
+                            wave_ballot(aox < INFINITY) & wave_ballot(aoy < INFINITY) & wave_ballot(aoz < INFINITY);
+    const bool has = wave_mask_bit(finite & wave_ballot(c.est < INFINITY));
+    const bool unsure = has & (!(c.second > c.est * 1.00001f) | !(t > kMinDist) | !(t < INFINITY));
+    if (wave_ballot(unsure) != 0) {
+        planes_exact<COUNT>(S, ro, rd, best, wk);
+        return;
+    }
+    best.distance = has ? t : INFINITY; best.object = has ? c.object : -1; best.t = has ? t : 0.0f;
 }
 
 template <int F, bool COUNT, class Stack>
-RT_HD void find_closest(const DevScene &S, v3 ro, v3 rd, int accel, int light, float clip, float occl, Closest &best, Stack &stk, Work &wk) {
+RT_HD void find_closest(SceneRef scene, v3 ro, v3 rd, int accel, int light, float clip, float occl, Closest &best, Stack &stk, Work &wk) {
+    SceneRef S = fresh(scene, rd.x);
     // light: >= 0 when the ray is a shadow ray towards that light.  When all lanes of the wave are
     // shadow rays towards the same light, planes that cannot shadow it are skipped.
     int32_t light_u = wave_uniform(light);
@@ -932,31 +1153,9 @@ RT_HD void find_closest(const DevScene &S, v3 ro, v3 rd, int accel, int light, f
     best.object = -1;
     best.t = 0;
     best.k = 0;
-    // planes (Plane::intersect, main.cpp:222-237).  A plane is skipped by the whole wave when no
-    // lane's ray faces it, or when a 1-ulp estimate of the quotient shows that no lane's hit could
-    // replace its current best; otherwise the exact quotient is formed by every lane (no divergence).
-    // For a normal that is exactly +-e_a the reference's dot products reduce exactly to the a-th
-    // components (x * 0 = +-0 and v + +-0 = v) as long as every component is finite; with a
-    // non-finite component they are NaN and the plane is missed, which `finite` reproduces.
-    // The order of the tests is free: closer() picks the same winner in any order.
-    float adx = fabsf(rd.x), ady = fabsf(rd.y), adz = fabsf(rd.z), aox = fabsf(ro.x), aoy = fabsf(ro.y), aoz = fabsf(ro.z);
-    const uint64_t finite = wave_ballot(adx < INFINITY) & wave_ballot(ady < INFINITY) & wave_ballot(adz < INFINITY) &
-                            wave_ballot(aox < INFINITY) & wave_ballot(aoy < INFINITY) & wave_ballot(aoz < INFINITY);
+    const v3 rinv = V3(shade_rcp(rd.x), shade_rcp(rd.y), shade_rcp(rd.z));  // estimates and box tests only, never a hit decision
+    if ((S.planes_skip_lights & light_bit) == 0) planes_pass<COUNT>(S, ro, rd, rinv, light_bit, best, wk);
     const bool meshes = (F & F_MESH) && S.n_meshes > 0;
-    for (int32_t i = 0; i < S.n_axis_planes; i += kAxisPlaneGroup) {
-        u32x16 g = load_u32x16(S.axis_planes + i);
-        pin_scalar(g);
-        plane_axis_test<COUNT>((int32_t)g[0], u2f(g[1]), (int32_t)g[2], g[3] & light_bit, ro, rd, finite, best, wk);
-        plane_axis_test<COUNT>((int32_t)g[4], u2f(g[5]), (int32_t)g[6], g[7] & light_bit, ro, rd, finite, best, wk);
-        plane_axis_test<COUNT>((int32_t)g[8], u2f(g[9]), (int32_t)g[10], g[11] & light_bit, ro, rd, finite, best, wk);
-        plane_axis_test<COUNT>((int32_t)g[12], u2f(g[13]), (int32_t)g[14], g[15] & light_bit, ro, rd, finite, best, wk);
-    }
-    for (int32_t i = 0; i < S.n_gen_planes; i += kPlaneGroup) {
-        u32x16 g = load_u32x16(S.gen_planes + i);
-        pin_scalar(g);
-        plane_gen_test<COUNT>(g, 0, light_bit, ro, rd, best, wk);
-        plane_gen_test<COUNT>(g, 8, light_bit, ro, rd, best, wk);
-    }
     if (F & F_QUADRIC)
     for (int32_t i = 0; i < S.n_spheres; i++) {
         QuadricHit q;
@@ -980,14 +1179,14 @@ RT_HD void find_closest(const DevScene &S, v3 ro, v3 rd, int accel, int light, f
         }
     }
     if (meshes) {
-    v3 winv = V3(safe_rcp(rd.x), safe_rcp(rd.y), safe_rcp(rd.z));
+    v3 winv = V3(safe_rcp_of(rd.x, rinv.x), safe_rcp_of(rd.y, rinv.y), safe_rcp_of(rd.z, rinv.z));
     v3 woi = ro * winv;
     bool nan_o = has_nan(ro), nan_d = has_nan(rd);
     bool valid = !(nan_o | nan_d);  // every triangle test fails on NaN inputs
     const int32_t n_meshes = S.n_meshes;
     for (int32_t i = 0; i < n_meshes; i++) {
         union { u32x16 raw; MeshHead h; } head;
-        head.raw = load_u32x16(S.meshes + i);
+        head.raw = load_u32x16(mesh_head_at(S, i, rd.y));
         int32_t idx = head.h.object;
         if (idx < 0) continue;  // wave-uniform
         MeshHit mh;
@@ -999,13 +1198,27 @@ RT_HD void find_closest(const DevScene &S, v3 ro, v3 rd, int accel, int light, f
     }
 }
 
+// The full hit record of a closest hit, lane by lane (the entry points that report records; the render kernels
+// shade through surface_shade below and never build one).
 template <int F, bool COUNT>
-RT_HD void resolve(const DevScene &S, const Closest &c, v3 ro, v3 rd, Surf &s, Work &wk) {
+RT_HD void resolve(SceneRef S, const Closest &c, v3 ro, v3 rd, Surf &s, Work &wk) {
     rt_object ob = S.objects[c.object];
+    s.frag = 0;
+    s.sub = 0;
+    TexRef none;
+    none.w = none.h = 1; none.texels = nullptr;
     if (ob.kind == RT_OBJ_PLANE) {
-        plane_surface<F, COUNT>(S, S.planes[ob.index], ro, rd, c.t, s, wk);
+        const rt_plane &pl = S.planes[ob.index];
+        const DevTexture *it = (F & F_TEXTURE) ? image_texture_of(S, S.materials[pl.material]) : nullptr;
+        v3 n = ld3(pl.normal);
+        plane_geo<COUNT>(n, normalize(n), ld3(pl.b1), ld3(pl.b2), it != nullptr, it ? tex_ref(*it) : none, ro, rd, c.t, s, wk);
+        s.material = pl.material;
     } else if ((F & F_MESH) && ob.kind == RT_OBJ_MESH) {
-        mesh_surface(S, S.meshes[ob.index], ro, rd, c.t, c.k, s);
+        int32_t orig;
+        mesh_geo(S, S.meshes[ob.index], ro, rd, c.t, c.k, s, orig);
+        s.material = S.tri_material[orig];
+        s.frag = S.tri_frag[orig];
+        s.sub = S.tri_sub[orig];
     } else if (!(F & F_QUADRIC)) {
         // unreachable: the scene has no object of another kind
     } else if (ob.kind == RT_OBJ_SPHERE) {
@@ -1014,14 +1227,19 @@ RT_HD void resolve(const DevScene &S, const Closest &c, v3 ro, v3 rd, Surf &s, W
         q.o = xform_point(sp.to_local, ro); q.d = xform_dir(sp.to_local, rd);
         q.t = c.t; q.cap = false; q.i = q.o + q.d * c.t;
         q.from_outside = !(fabsf(q.o.x) < 1 && fabsf(q.o.y) < 1 && fabsf(q.o.z) < 1);
-        sphere_surface<F, COUNT>(S, sp, q, s, wk);
+        const DevTexture *it = (F & F_TEXTURE) ? image_texture_of(S, S.materials[sp.material]) : nullptr;
+        sphere_geo<COUNT>(sp, q, it != nullptr, it ? tex_ref(*it) : none, s, wk);
+        s.material = sp.material;
     } else {
         const rt_cone &cn = S.cones[ob.index];
         QuadricHit q;
         q.d = xform_dir(cn.to_local, rd); q.o = xform_point(cn.to_local, ro);
         q.t = c.t; q.cap = c.k != 0; q.from_outside = true;
-        q.i = q.cap ? q.d * c.t + q.o : q.o + q.d * c.t;
-        cone_surface<F, COUNT>(S, cn, q, s, wk);
+        q.i = select3(q.cap, q.d * c.t + q.o, q.o + q.d * c.t);
+        const DevTexture *it = (F & F_TEXTURE) ? image_texture_of(S, S.materials[cn.cap.material]) : nullptr;
+        cone_geo<COUNT>(cn, q, it != nullptr, it ? tex_ref(*it) : none, s, wk);
+        s.material = cn.material;
+        s.sub = q.cap ? 1 : 0;
     }
 }
 
@@ -1037,10 +1255,19 @@ RT_HD void fill_hit(rt_hit_record &h, const Closest &c, const Surf &s) {
         h.uv[0] = s.uv.x; h.uv[1] = s.uv.y;
     }
 }
+// the record of a closest-hit query (a miss included)
+template <int F, bool COUNT>
+RT_HD void hit_record(SceneRef S, const Closest &c, v3 ro, v3 rd, rt_hit_record &h, Work &wk) {
+    Surf s;
+    s.frag = 0; s.sub = 0; s.from_outside = true; s.has_texel = false; s.material = 0;
+    s.point = V3(0, 0, 0); s.normal = V3(0, 0, 0); s.uv.x = s.uv.y = 0;
+    if (c.object >= 0) resolve<F, COUNT>(S, c, ro, rd, s, wk);
+    fill_hit(h, c, s);
+}
 
 // Object::intersect for one object without the closest-hit filters (the per-object parity entry)
 template <bool COUNT, class Stack>
-RT_HD void intersect_object(const DevScene &S, int32_t k, v3 ro, v3 rd, int accel, rt_hit_record &out, Stack &stk, Work &wk) {
+RT_HD void intersect_object(SceneRef S, int32_t k, v3 ro, v3 rd, int accel, rt_hit_record &out, Stack &stk, Work &wk) {
     Closest c;
     c.object = -1; c.distance = INFINITY; c.t = 0; c.k = 0;
     bool from_outside = true;
@@ -1061,7 +1288,7 @@ RT_HD void intersect_object(const DevScene &S, int32_t k, v3 ro, v3 rd, int acce
         if (hit) { c.t = q.t; c.k = q.cap ? 1 : 0; c.distance = q.distance; from_outside = q.from_outside; }
     }
     Surf s;
-    s.frag = 0; s.sub = 0; s.from_outside = from_outside;
+    s.frag = 0; s.sub = 0; s.from_outside = from_outside; s.has_texel = false; s.material = 0;
     s.point = V3(0, 0, 0); s.normal = V3(0, 0, 0); s.uv.x = s.uv.y = 0;
     if (hit) {
         c.object = k;
@@ -1083,100 +1310,299 @@ RT_HD v3 refract_dir(v3 i, v3 n, float index) {
     return a * alpha + b * beta;
 }
 
-// What PhongModel (main.cpp:642-695) needs while the shadow rays of one hit are in flight.
+// What PhongModel (main.cpp:642-695) and the recursion of trace_ray (main.cpp:728-757) need of a hit: the surface
+// and the material's terms, per lane, in registers.
 struct ShadeCtx {
     v3 point, normal, d_in;  // d_in: direction of the ray that produced the hit (the view vector is normalize(-d_in))
     v3 color;                // running sum, starts at ambient_light * material.ambient
     v3 dc;                   // diffuse colour (texture(uv) or material.diffuse), x5 for image textures
-    uint32_t occlusion_px;   // RGBA8 texel of the occlusion map (image-textured surfaces)
+    v3 spec;                 // material.specular
     float shininess;
-    int32_t material;
-    bool from_outside;
+    uint32_t occlusion_px;   // RGBA8 texel of the occlusion map (image-textured surfaces)
+    uint32_t flags;          // kShadeImage, kShadeOutside
+    float refl, refr, ratio; // material.reflectiveness / refractiveness / refractive_ratio (kernels with secondary rays)
 };
+enum : uint32_t { kShadeImage = 1u, kShadeOutside = 2u };
 
-// While the shadow queries of a hit are traced its ShadeCtx is parked in per-lane storage supplied by
-// the Stack policy (LDS columns on the GPU: cold_put(slot, float) / cold_get(slot)), so that it holds no
-// registers during the traversal; without this the 96-register build of the render kernel spilled to
-// scratch memory.
-constexpr int kColdSlots = 23;  // 22 without secondary rays: see cold_slots()
+// The material of a hit in the form shading uses it.  Fetched for a whole wave at once the fields are scalar
+// registers; the same code serves values fetched per lane.
+struct Mat {
+    v3 ambient, diffuse, specular;
+    float shininess, refl, refr, ratio;
+    uint32_t tex_wh, tex_lo, tex_hi;
+};
+RT_HD Mat mat_of(const u32x16 &m) {
+    Mat r;
+    r.ambient = V3(u2f(m[0]), u2f(m[1]), u2f(m[2])); r.diffuse = V3(u2f(m[3]), u2f(m[4]), u2f(m[5]));
+    r.specular = V3(u2f(m[6]), u2f(m[7]), u2f(m[8]));
+    r.shininess = u2f(m[9]); r.refl = u2f(m[10]); r.refr = u2f(m[11]); r.ratio = u2f(m[12]);
+    r.tex_wh = m[13]; r.tex_lo = m[14]; r.tex_hi = m[15];
+    return r;
+}
+
+// The start of PhongModel for one hit (main.cpp:646, 664-676): ambient term, diffuse colour, shininess.
+template <int F, bool COUNT>
+RT_HD void shade_begin(SceneRef S, const Mat &m, const SurfGeo &g, v3 d_in, ShadeCtx &sc, Work &wk) {
+    sc.point = g.point; sc.normal = g.normal; sc.d_in = d_in; sc.occlusion_px = 0;
+    sc.flags = g.from_outside ? kShadeOutside : 0u;
+    sc.color = m.ambient;
+    sc.dc = m.diffuse;
+    sc.spec = m.specular;
+    sc.shininess = m.shininess;
+    sc.refl = m.refl; sc.refr = m.refr; sc.ratio = m.ratio;
+    const int kind = (F & F_TEXTURE) ? mat_tex_kind(m.tex_lo) : -1;
+    if (kind == RT_TEX_IMAGE) {
+        uint32_t color = g.tex_color, occlusion = g.tex_occlusion, roughness = g.tex_roughness;
+        if (!g.has_texel) {  // surfaces without a normal-mapped branch (cones, meshes)
+            u4 t = tex_texel<COUNT>(mat_tex_ref(m.tex_wh, m.tex_lo, m.tex_hi), g.uv, wk);
+            color = t.x; occlusion = t.z; roughness = t.w;
+        }
+        sc.occlusion_px = occlusion;
+        sc.flags |= kShadeImage;
+        sc.dc = tex_base_color(S, color) * 5.f;  // diffuse *= 5 (main.cpp:673) commutes with the NdotL factor
+        // .5 / pow(roughness, 4) - .5 in double (main.cpp:674): r*r is exact in double, its square rounds once
+        double r2 = (double)unpack_rgba8(roughness).x;
+        r2 = r2 * r2;
+        sc.shininess = (float)(.5 / (r2 * r2) - .5);
+    } else if (kind >= 0) {
+        sc.dc = tex_procedural(kind, g.uv);
+    }
+}
+
+// While a shadow query of a hit is traced its ShadeCtx is parked in per-lane storage supplied by the Stack
+// policy (LDS columns on the GPU: cold_put(slot, float) / cold_get(slot)), so that it holds no registers during
+// the traversal.  Only a query that is actually made parks: most shadow rays of a lit room are answered without
+// one (LightCull) and their hits never leave the registers.
 RT_HD float i2f(int32_t i) { return u2f((uint32_t)i); }
 template <class Stack>
 RT_HD void cold_put3(Stack &stk, int slot, v3 v) { stk.cold_put(slot, v.x); stk.cold_put(slot + 1, v.y); stk.cold_put(slot + 2, v.z); }
 template <class Stack>
 RT_HD v3 cold_get3(Stack &stk, int slot) { return V3(stk.cold_get(slot), stk.cold_get(slot + 1), stk.cold_get(slot + 2)); }
-enum : int { kColdPoint = 0, kColdNormal = 3, kColdDirIn = 6, kColdColor = 9, kColdDc = 12, kColdOcclusion = 15, kColdShininess = 16,
-             kColdMaterial = 17, kColdL = 18, kColdLightR = 21, kColdOutside = 22 };
-// from_outside only matters for reflection / refraction: the last slot
-constexpr int cold_slots(int features) { return (features & F_SECONDARY) ? kColdSlots : kColdOutside; }
+enum : int { kColdPoint = 0, kColdNormal = 3, kColdDirIn = 6, kColdColor = 9, kColdDc = 12, kColdSpec = 15, kColdShininess = 18,
+             kColdOcclusion = 19, kColdFlags = 20, kColdRefl = 21, kColdRefr = 22, kColdRatio = 23, kColdSlots = 24 };
+// scenes without textures and secondary rays park neither texel nor flags nor the blend factors
+constexpr int cold_slots(int features) { return (features & F_SECONDARY) ? kColdSlots : (features & F_TEXTURE) ? kColdRefl : kColdOcclusion; }
 template <int F, class Stack>
 RT_HD void park_shade(Stack &stk, const ShadeCtx &sc) {
     cold_put3(stk, kColdPoint, sc.point); cold_put3(stk, kColdNormal, sc.normal);
     cold_put3(stk, kColdDirIn, sc.d_in); cold_put3(stk, kColdColor, sc.color); cold_put3(stk, kColdDc, sc.dc);
-    stk.cold_put(kColdOcclusion, u2f(sc.occlusion_px)); stk.cold_put(kColdShininess, sc.shininess);
-    stk.cold_put(kColdMaterial, i2f(sc.material));
-    if (F & F_SECONDARY) stk.cold_put(kColdOutside, sc.from_outside ? 1.0f : 0.0f);
+    cold_put3(stk, kColdSpec, sc.spec); stk.cold_put(kColdShininess, sc.shininess);
+    if (F & (F_TEXTURE | F_SECONDARY)) { stk.cold_put(kColdOcclusion, u2f(sc.occlusion_px)); stk.cold_put(kColdFlags, u2f(sc.flags)); }
+    if (F & F_SECONDARY) { stk.cold_put(kColdRefl, sc.refl); stk.cold_put(kColdRefr, sc.refr); stk.cold_put(kColdRatio, sc.ratio); }
 }
 template <int F, class Stack>
 RT_HD void unpark_shade(Stack &stk, ShadeCtx &sc) {
     sc.point = cold_get3(stk, kColdPoint); sc.normal = cold_get3(stk, kColdNormal);
     sc.d_in = cold_get3(stk, kColdDirIn); sc.color = cold_get3(stk, kColdColor); sc.dc = cold_get3(stk, kColdDc);
-    sc.occlusion_px = (uint32_t)f2i(stk.cold_get(kColdOcclusion)); sc.shininess = stk.cold_get(kColdShininess);
-    sc.material = f2i(stk.cold_get(kColdMaterial));
-    sc.from_outside = true;
-    if (F & F_SECONDARY) sc.from_outside = stk.cold_get(kColdOutside) != 0.0f;
+    sc.spec = cold_get3(stk, kColdSpec); sc.shininess = stk.cold_get(kColdShininess);
+    if (F & (F_TEXTURE | F_SECONDARY)) { sc.occlusion_px = (uint32_t)f2i(stk.cold_get(kColdOcclusion)); sc.flags = (uint32_t)f2i(stk.cold_get(kColdFlags)); }
+    else { sc.occlusion_px = 0; sc.flags = kShadeOutside; }  // (no image textures, and nobody asks which side was hit)
+    if (F & F_SECONDARY) { sc.refl = stk.cold_get(kColdRefl); sc.refr = stk.cold_get(kColdRefr); sc.ratio = stk.cold_get(kColdRatio); }
+    else { sc.refl = sc.refr = sc.ratio = 0; }
 }
 
+// One object's part of turning closest hits into shading contexts (Hit's fields, main.cpp:45-53, then the start of
+// PhongModel), for the lanes that hit the object whose record (g: first half of its ObjRec, mr: its material) was
+// fetched for the whole wave.
 template <int F, bool COUNT>
-RT_HD void shade_begin(const DevScene &S, const Surf &s, v3 d_in, ShadeCtx &sc, Work &wk) {
-    const rt_material &m = S.materials[s.material];
-    sc.point = s.point; sc.normal = s.normal; sc.d_in = d_in; sc.occlusion_px = 0;
-    sc.material = s.material; sc.from_outside = s.from_outside;
-    sc.color = ld3(S.ambient) * ld3(m.ambient);
-    const DevTexture *tex = ((F & F_TEXTURE) && m.texture >= 0) ? &S.textures[m.texture] : nullptr;
-    const DevTexture *img = (tex && tex->kind == RT_TEX_IMAGE) ? tex : nullptr;
-    sc.dc = ld3(m.diffuse);
-    if (tex && !img) sc.dc = tex_procedural(tex->kind, s.uv);
-    sc.shininess = m.shininess;
-    if (img) {
-        u4 texel = s.texel;
-        if (!s.has_texel) texel = tex_texel<COUNT>(*img, s.uv, wk);  // surfaces without a normal-mapped branch (cones, meshes)
-        sc.occlusion_px = texel.z;
-        sc.dc = tex_base_color(S, texel.x) * 5.f;  // diffuse *= 5 (main.cpp:673) commutes with the NdotL factor
-        // .5 / pow(roughness, 4) - .5 in double (main.cpp:674): r*r is exact in double, its square rounds once
-        double r2 = (double)unpack_rgba8(texel.w).x;
-        r2 = r2 * r2;
-        sc.shininess = (float)(.5 / (r2 * r2) - .5);
+RT_HD void shade_object(SceneRef S, const u32x16 &g, const u32x16 &mr, const Closest &c, v3 ro, v3 rd, ShadeCtx &sc, Work &wk) {
+    const int32_t kind = (int32_t)g[0], index = (int32_t)g[1];
+    Mat m = mat_of(mr);
+    const bool image = (F & F_TEXTURE) && mat_tex_kind(m.tex_lo) == RT_TEX_IMAGE;
+    const TexRef tex = mat_tex_ref(m.tex_wh, m.tex_lo, m.tex_hi);
+    SurfGeo s;
+    if (kind == RT_OBJ_PLANE) {
+        plane_geo<COUNT>(V3(u2f(g[4]), u2f(g[5]), u2f(g[6])), V3(u2f(g[7]), u2f(g[8]), u2f(g[9])), V3(u2f(g[10]), u2f(g[11]), u2f(g[12])),
+                         V3(u2f(g[13]), u2f(g[14]), u2f(g[15])), image, tex, ro, rd, c.t, s, wk);
+        shade_begin<F, COUNT>(S, m, s, rd, sc, wk);
+    } else if ((F & F_MESH) && kind == RT_OBJ_MESH) {
+        int32_t orig;
+        mesh_geo(S, S.meshes[index], ro, rd, c.t, c.k, s, orig);
+        if ((int32_t)g[2] >= 0) {
+            shade_begin<F, COUNT>(S, m, s, rd, sc, wk);
+        } else {  // triangles with materials of their own: the same idea once more, over the materials
+            const int32_t mine = S.tri_material[orig];
+            bool left = true;
+            while (wave_ballot(left) != 0) {
+                if (left) {
+                    const int32_t mi = wave_uniform(mine);
+                    if (mine == uniform_alias(mi)) {
+                        left = false;
+                        u32x16 mr2 = load_u32x16(S.mat_recs + mi);
+                        pin_scalar(mr2);
+                        shade_begin<F, COUNT>(S, mat_of(mr2), s, rd, sc, wk);
+                    }
+                }
+            }
+        }
+    } else if (!(F & F_QUADRIC)) {
+        // unreachable: the scene has no object of another kind
+    } else if (kind == RT_OBJ_SPHERE) {
+        const rt_sphere &sp = S.spheres[index];
+        QuadricHit q;
+        q.o = xform_point(sp.to_local, ro); q.d = xform_dir(sp.to_local, rd);
+        q.t = c.t; q.cap = false; q.i = q.o + q.d * c.t;
+        q.from_outside = !(fabsf(q.o.x) < 1 && fabsf(q.o.y) < 1 && fabsf(q.o.z) < 1);
+        sphere_geo<COUNT>(sp, q, image, tex, s, wk);
+        shade_begin<F, COUNT>(S, m, s, rd, sc, wk);
+    } else {
+        const rt_cone &cn = S.cones[index];
+        QuadricHit q;
+        q.d = xform_dir(cn.to_local, rd); q.o = xform_point(cn.to_local, ro);
+        q.t = c.t; q.cap = c.k != 0; q.from_outside = true;
+        q.i = select3(q.cap, q.d * c.t + q.o, q.o + q.d * c.t);
+        cone_geo<COUNT>(cn, q, image, tex, s, wk);
+        shade_begin<F, COUNT>(S, m, s, rd, sc, wk);
     }
 }
-// one light's contribution (main.cpp:658-685); L is the normalised direction to the light
+
+// From the closest hits of a wave to shading contexts.  The lanes of a wave mostly hit the same object (an 8x8
+// pixel block on one wall): the wave fetches that object's record and material ONCE through scalar loads and every
+// lane resolves its hit with them -- no per-lane chain of dependent loads (object -> plane -> material ->
+// texture).  A wave whose lanes hit several objects takes the object of its first unresolved lane, resolves the
+// lanes that hit it, and repeats while lanes are left.  A lane without a hit gets a NaN point (its shadow rays miss
+// everything); its other fields are not meaningful and nobody uses them.
+template <int F, bool COUNT, class Stack>
+RT_HD void surface_shade(SceneRef scene, const Closest &c, bool hit, v3 ro, v3 rd, ShadeCtx &sc, Stack &stk, Work &wk) {
+    SceneRef S = fresh(scene, c.t);
+    const uint64_t hits = wave_ballot(hit);
+    if (hits != 0) {
+        const int32_t obj = wave_value_at(c.object, hits);  // (of the first lane with a hit)
+        if (wave_ballot(hit & (c.object != uniform_alias(obj))) == 0) {
+            // one object: straight code for all lanes (a lane without a hit has c.t = 0, c.k = 0 and computes a value nobody uses)
+            const char *rec = obj_rec_at(S, obj, c.distance);
+            u32x16 g = load_u32x16(rec), mr = load_u32x16(rec + 64);
+            pin_scalar(g); pin_scalar(mr);
+            shade_object<F, COUNT>(S, g, mr, c, ro, rd, sc, wk);
+        } else {
+            // several objects: one after the other, each for the lanes that hit it.  The results go through the parking
+            // columns: a context built up in registers around the loop would be carried, and copied, in every round.
+            bool todo = hit;
+            while (wave_ballot(todo) != 0) {
+                if (todo) {
+                    const int32_t o2 = wave_uniform(c.object);  // (the first lane that is still to do)
+                    if (c.object == uniform_alias(o2)) {
+                        todo = false;
+                        const char *rec = obj_rec_at(S, o2, c.distance);
+                        u32x16 g = load_u32x16(rec), mr = load_u32x16(rec + 64);
+                        pin_scalar(g); pin_scalar(mr);
+                        ShadeCtx mine;
+                        shade_object<F, COUNT>(S, g, mr, c, ro, rd, mine, wk);
+                        park_shade<F>(stk, mine);
+                    }
+                }
+            }
+            unpark_shade<F>(stk, sc);
+        }
+    }
+    if (!hit) sc.point = V3(NAN, NAN, NAN);
+}
+
+// one light's contribution (main.cpp:658-685); L is the normalised direction to the light, r its distance
 template <bool COUNT>
-RT_HD void shade_light(const DevScene &S, ShadeCtx &sc, int l, v3 L, float r, Work &wk) {
+RT_HD void shade_light(ShadeCtx &sc, v3 light_color, v3 L, float r, Work &wk) {
     if (COUNT) wk.shade++;
-    const rt_material &m = S.materials[sc.material];
     float NdotL = clamp01(dot(sc.normal, L));
     v3 term = sc.dc * NdotL;
-    v3 spec_col = ld3(m.specular);
     // the view vector, the mirrored light direction and the lobe only where the material has a specular term (a
     // zero coefficient multiplies a finite lobe value: the sum is the same without it)
-    if (spec_col.x != 0.0f || spec_col.y != 0.0f || spec_col.z != 0.0f) {
+    if (sc.spec.x != 0.0f || sc.spec.y != 0.0f || sc.spec.z != 0.0f) {
         v3 view = normalize(-sc.d_in);
         v3 R = reflect(-L, sc.normal);
         float VdotR = clamp01(dot(view, R));
-        term = term + spec_col * shade_pow(VdotR, sc.shininess);
+        term = term + sc.spec * shade_pow(VdotR, sc.shininess);
     }
     r = (r < 0.1f) ? 0.1f : r;
     float inv_r = shade_rcp(r);
-    term = ld3(S.light_color + 3 * l) * term;
+    term = light_color * term;
     sc.color = sc.color + term * (1.3f * inv_r * inv_r);
 }
-template <int F, bool COUNT>
-RT_HD v3 shade_end(const DevScene &S, const ShadeCtx &sc, Work &wk) {
-    const rt_material &m = S.materials[sc.material];
-    const DevTexture *img = (F & F_TEXTURE) ? image_texture_of(S, m) : nullptr;
+// the end of PhongModel (main.cpp:688-692)
+RT_HD v3 shade_end(const ShadeCtx &sc) {
     v3 color = sc.color;
-    if (img) color = color * unpack_rgb8(sc.occlusion_px);
+    if (sc.flags & kShadeImage) color = color * unpack_rgb8(sc.occlusion_px);
     else color = color * 4.0f;
     return color * 2.0f;
+}
+
+// One shadow query per light for the hits of a wave (main.cpp:650-685), all lanes in step: the light index is
+// wave-uniform.  A lane without a hit (sc.point NaN) sends NaN rays, which miss everything at no cost.
+//
+// Direction and distance to the light: L = normalize(light - point) and |light - point| exactly as the reference
+// forms them for every lane whose shadow ray is traced -- they are that ray.  A lane whose ray lies outside every
+// cone of a cullable light (LightCull) traces nothing; there the two values only enter the colour arithmetic and
+// come from the hardware's 1-ulp reciprocal square root.  Which form a lane gets depends on its own ray alone, so a
+// pixel's value does not depend on which other rays share its wave.
+template <int F, bool COUNT, class Stack>
+RT_HD void shade_lights(SceneRef scene, bool hit, int accel, ShadeCtx &sc, Stack &stk, Work &wk) {
+    SceneRef S0 = fresh(scene, sc.point.x);
+    const int32_t n_lights = S0.n_lights;
+    const uint32_t cullable_lights = S0.cullable_lights;
+    for (int32_t l = 0; l < n_lights; l++) {
+        bool traced = hit;  // this lane's shadow ray has to be traced
+        {
+            SceneRef S = fresh(scene, sc.point.y);
+            if (l < 32 && ((cullable_lights >> l) & 1u)) {
+                const char *rec = light_rec_at(S, l, sc.point.z);
+                u32x16 lr = load_u32x16(rec), lc = load_u32x16(rec + 64);
+                pin_scalar(lr); pin_scalar(lc);
+                v3 Lv = V3(u2f(lr[0]), u2f(lr[1]), u2f(lr[2])) - sc.point;
+                v3 La = Lv * shade_rsq(dot(Lv, Lv));
+                // slots are filled in order and an unused one holds cos = 2 (never inside): stop at the first
+                bool in = !(dot(La, V3(u2f(lc[0]), u2f(lc[1]), u2f(lc[2]))) < u2f(lc[3]));
+                if (lc[7] != kUnusedCone) {
+                    in |= !(dot(La, V3(u2f(lc[4]), u2f(lc[5]), u2f(lc[6]))) < u2f(lc[7]));
+                    if (lc[11] != kUnusedCone) {
+                        in |= !(dot(La, V3(u2f(lc[8]), u2f(lc[9]), u2f(lc[10]))) < u2f(lc[11]));
+                        if (lc[15] != kUnusedCone) in |= !(dot(La, V3(u2f(lc[12]), u2f(lc[13]), u2f(lc[14]))) < u2f(lc[15]));
+                    }
+                }
+                traced = hit & in;
+            }
+        }
+        const uint64_t traced_mask = wave_ballot(traced);
+        bool lit = hit;
+        if (traced_mask != 0) {  // (wave-uniform)
+            const char *rec = light_rec_at(fresh(scene, sc.point.y), l, sc.point.z);
+            u32x16 lr = load_u32x16(rec);
+            pin_scalar(lr);
+            v3 Lv = V3(u2f(lr[0]), u2f(lr[1]), u2f(lr[2])) - sc.point;
+            float len = sqrtf(dot(Lv, Lv));
+            v3 L = Lv * (1.0f / len);       // glm::normalize(light - point)
+            if (!traced) L = V3(NAN, NAN, NAN);
+            park_shade<F>(stk, sc);
+            Closest cs;
+            // |L| = 1, so the local ray parameter equals the world distance up to rounding: clip there
+            find_closest<F, COUNT>(scene, sc.point + L * kEps, L, accel, l, len * 1.001f + 1e-3f, len, cs, stk, wk);
+            unpark_shade<F>(stk, sc);
+            // (the distance again from the parked point and the light's record: nothing but the parked values lives across the query)
+            u32x16 lr2 = load_u32x16(light_rec_at(fresh(scene, sc.point.y), l, sc.point.z));
+            pin_scalar(lr2);
+            v3 Lv2 = V3(u2f(lr2[0]), u2f(lr2[1]), u2f(lr2[2])) - sc.point;
+            float len2 = sqrtf(dot(Lv2, Lv2));
+            lit = hit & !(wave_mask_bit(traced_mask) & (cs.distance < len2));
+        }
+        if (hit) {
+            wk.rays_shadow++;
+            if (wave_mask_bit(traced_mask)) wk.shadow_q++;
+        }
+        {
+            u32x16 lr = load_u32x16(light_rec_at(fresh(scene, sc.point.y), l, sc.point.z));
+            pin_scalar(lr);
+            v3 Lv = V3(u2f(lr[0]), u2f(lr[1]), u2f(lr[2])) - sc.point;
+            float d2 = dot(Lv, Lv);
+            float ri = shade_rsq(d2);
+            v3 L = Lv * ri;
+            float r = d2 * ri;
+            if (traced_mask != 0) {  // the exact forms for the lanes whose ray was traced
+                float len = sqrtf(d2);
+                v3 Le = Lv * (1.0f / len);
+                const bool mine = wave_mask_bit(traced_mask);
+                L = select3(mine, Le, L); r = mine ? len : r;
+            }
+            if (lit) shade_light<COUNT>(sc, V3(u2f(lr[4]), u2f(lr[5]), u2f(lr[6])), L, r, wk);
+        }
+    }
 }
 
 // ---------------------------------------------------------------- trace loop
@@ -1196,96 +1622,36 @@ RT_HD v3 shade_end(const DevScene &S, const ShadeCtx &sc, Work &wk) {
 //   bool next(v3 &o, v3 &d);  void done(v3 radiance);  rt_hit_record *first_hit();
 struct Pending { v3 o, d; float w; int32_t depth; };
 
-template <int F, bool COUNT, class Stack>
-RT_HD void shade_lights(const DevScene &S, bool hit, int accel, Stack &stk, Work &wk);
-
 // The same for scenes without reflective or refractive materials, where every primary ray ends in
 // direct lighting: primary query, then one shadow query per light, as plain nested loops.  The lanes
 // of a wave stay in step (they have the same number of taps and lights), so the light index is a
-// wave-uniform value and neither a ray stage nor a pending stack has to be carried.  A lane without
-// a hit sends NaN shadow rays, which miss everything at no cost.
+// wave-uniform value and neither a ray stage nor a pending stack has to be carried.
 template <int F, bool COUNT, class Stack, class Source>
-RT_HD void trace_loop_direct(const DevScene &S, int accel, Stack &stk, Work &wk, Source &src) {
+RT_HD void trace_loop_direct(SceneRef S, int accel, Stack &stk, Work &wk, Source &src) {
     v3 o, d;
-    bool live = src.next(o, d);
+    bool live = src.next(o, d);  // (a source may hand a lane no ray while others get one: all lanes call next() alike, in step)
+    bool more = true;
     while (wave_ballot(live) != 0) {
         Closest c;
         find_closest<F, COUNT>(S, o, d, accel, -1, INFINITY, -INFINITY, c, stk, wk);
         if (live) wk.rays_primary++;
         bool hit = live & (c.object >= 0);
-        Surf s;
-        if (hit) resolve<F, COUNT>(S, c, o, d, s, wk);
         rt_hit_record *fh = src.first_hit();
-        if (fh && live) fill_hit(*fh, c, s);
-        {
-            ShadeCtx sc;
-            sc.point = V3(NAN, NAN, NAN);
-            if (hit) shade_begin<F, COUNT>(S, s, d, sc, wk);
-            if (hit) park_shade<F>(stk, sc); else cold_put3(stk, kColdPoint, sc.point);
-        }
-        shade_lights<F, COUNT>(S, hit, accel, stk, wk);
+        if (fh && live) hit_record<F, COUNT>(S, c, o, d, *fh, wk);
+        ShadeCtx sc;
+        surface_shade<F, COUNT>(S, c, hit, o, d, sc, stk, wk);
+        shade_lights<F, COUNT>(S, hit, accel, sc, stk, wk);
         v3 radiance = V3(0, 0, 0);
-        if (hit) {
-            ShadeCtx sc;
-            unpark_shade<F>(stk, sc);
-            radiance = radiance + shade_end<F, COUNT>(S, sc, wk) * 1.0f;
-        }
+        if (hit) radiance = radiance + shade_end(sc) * 1.0f;
         if (live) src.done(radiance);
-        live = live && src.next(o, d);
+        more = src.next(o, d);
+        live = live & more;
     }
-}
-
-// One shadow query per light for the parked hit (main.cpp:650-685), for all lanes of the wave in
-// step: the light index is wave-uniform.  A lane without a hit (`hit` false, parked point NaN) sends
-// NaN rays, which miss everything at no cost.
-template <int F, bool COUNT, class Stack>
-RT_HD void shade_lights(const DevScene &S, bool hit, int accel, Stack &stk, Work &wk) {
-    const int32_t n_lights = S.n_lights;
-    for (int32_t l = 0; l < n_lights; l++) {
-        // shadow ray (main.cpp:650-656): from point + EPS * L towards light l
-        v3 point = cold_get3(stk, kColdPoint);
-        v3 lp = ld3(S.light_pos + 3 * l);
-        v3 L = normalize(lp - point);
-        float light_r = distance(point, lp);
-        Closest cs;
-        cs.distance = INFINITY;
-        bool query = true;
-        if (l < 32 && ((S.cullable_lights >> l) & 1u)) {
-            u32x16 lc = load_u32x16(S.light_cull + l);
-            pin_scalar(lc);
-            // slots are filled in order and an unused one holds cos = 2 (never inside): stop at the first
-            bool in = !(dot(L, V3(u2f(lc[0]), u2f(lc[1]), u2f(lc[2]))) < u2f(lc[3]));
-            if (lc[7] != kUnusedCone) {
-                in |= !(dot(L, V3(u2f(lc[4]), u2f(lc[5]), u2f(lc[6]))) < u2f(lc[7]));
-                if (lc[11] != kUnusedCone) {
-                    in |= !(dot(L, V3(u2f(lc[8]), u2f(lc[9]), u2f(lc[10]))) < u2f(lc[11]));
-                    if (lc[15] != kUnusedCone) in |= !(dot(L, V3(u2f(lc[12]), u2f(lc[13]), u2f(lc[14]))) < u2f(lc[15]));
-                }
-            }
-            bool near_mesh = hit & in;
-            query = wave_ballot(near_mesh) != 0;  // nothing can lie between these points and the light
-        }
-        // |L| = 1, so the local ray parameter equals the world distance up to rounding: clip there
-        if (query) {
-            cold_put3(stk, kColdL, L); stk.cold_put(kColdLightR, light_r);
-            find_closest<F, COUNT>(S, point + L * kEps, L, accel, l, light_r * 1.001f + 1e-3f, light_r, cs, stk, wk);
-            L = cold_get3(stk, kColdL); light_r = stk.cold_get(kColdLightR);
-        }
-        if (hit) {
-            wk.rays_shadow++;
-            if (query) wk.shadow_q++;
-            if (!(cs.distance < light_r)) {
-                ShadeCtx sc;
-                unpark_shade<F>(stk, sc);
-                shade_light<COUNT>(S, sc, l, L, light_r, wk);
-                cold_put3(stk, kColdColor, sc.color);
-            }
-        }
-    }
+    (void)more;
 }
 
 template <int F, bool COUNT, class Stack, class Source>
-RT_HD void trace_loop(const DevScene &S, int max_depth, int accel, Stack &stk, Work &wk, Source &src) {
+RT_HD void trace_loop(SceneRef S, int max_depth, int accel, Stack &stk, Work &wk, Source &src) {
     if (!(F & F_SECONDARY)) {
         trace_loop_direct<F, COUNT>(S, accel, stk, wk, src);
         return;
@@ -1304,39 +1670,31 @@ RT_HD void trace_loop(const DevScene &S, int max_depth, int accel, Stack &stk, W
         find_closest<F, COUNT>(S, o, d, accel, -1, INFINITY, -INFINITY, c, stk, wk);
         if (primary) wk.rays_primary++; else wk.rays_secondary++;
         bool hit = c.object >= 0;
-        Surf s;
-        if (hit) resolve<F, COUNT>(S, c, o, d, s, wk);
         if (primary) {
             rt_hit_record *fh = src.first_hit();
-            if (fh) fill_hit(*fh, c, s);
+            if (fh) hit_record<F, COUNT>(S, c, o, d, *fh, wk);
         }
         primary = false;
-        {
-            ShadeCtx sc;
-            sc.point = V3(NAN, NAN, NAN);
-            if (hit) shade_begin<F, COUNT>(S, s, d, sc, wk);
-            if (hit) park_shade<F>(stk, sc); else cold_put3(stk, kColdPoint, sc.point);
-        }
-        shade_lights<F, COUNT>(S, hit, accel, stk, wk);
+        ShadeCtx sc;
+        surface_shade<F, COUNT>(S, c, hit, o, d, sc, stk, wk);
+        shade_lights<F, COUNT>(S, hit, accel, sc, stk, wk);
         if (hit) {
-            ShadeCtx sc;
-            unpark_shade<F>(stk, sc);
-            const rt_material &m = S.materials[sc.material];
-            v3 local = shade_end<F, COUNT>(S, sc, wk);
-            float refl = m.reflectiveness, refr = m.refractiveness;
-            float ratio = m.refractive_ratio;
+            v3 local = shade_end(sc);
+            float refl = sc.refl, refr = sc.refr;
+            float ratio = sc.ratio;
+            const bool from_outside = (sc.flags & kShadeOutside) != 0;
             float w_after_refl = refl > 0 ? weight * (1 - refl) : weight;
             float w_local = refr > 0 ? w_after_refl * ratio : w_after_refl;
             radiance = radiance + local * w_local;
             int cd = depth + 1;
             bool deeper = cd <= max_depth, have_next = false;
             if (refr > 0 && deeper) {
-                float index = sc.from_outside ? refr : 1 / refr;
+                float index = from_outside ? refr : 1 / refr;
                 v3 rdir = refract_dir(sc.d_in, sc.normal, index);
                 o = sc.point + rdir * kEps; d = rdir;
                 have_next = true;
             }
-            if (refl > 0 && sc.from_outside && deeper) {
+            if (refl > 0 && from_outside && deeper) {
                 v3 rdir = reflect(sc.d_in, sc.normal);
                 v3 ro2 = sc.point + rdir * kEps;
                 float rw = weight * refl;
@@ -1371,7 +1729,7 @@ struct OneRay {
     RT_HD rt_hit_record *first_hit() { return hit; }
 };
 template <int F, bool COUNT, class Stack>
-RT_HD v3 trace(const DevScene &S, v3 ro, v3 rd, int max_depth, int accel, Stack &stk, Work &wk, rt_hit_record *first_hit) {
+RT_HD v3 trace(SceneRef S, v3 ro, v3 rd, int max_depth, int accel, Stack &stk, Work &wk, rt_hit_record *first_hit) {
     OneRay src;
     src.o = ro; src.d = rd; src.radiance = V3(0, 0, 0); src.hit = first_hit; src.taken = false;
     trace_loop<F, COUNT>(S, max_depth, accel, stk, wk, src);
@@ -1399,15 +1757,15 @@ RT_HD float tap_weight(int mode, int k) {
 }
 // offset of column / row a of the m x m GRID taps from the pixel's corner
 RT_HD float grid_offset(int a, int m, float s) { return ((float)a + 0.5f) / (float)m * s; }
-RT_HD v3 primary_dir(const Camera &c, int mode, int m, int i, int j, int k, float &weight) {
+// dx, dy: the pixel's corner X + i*s, Y - j*s (main.cpp:1244-1245; the one-tap mode adds its half pixel to the same sums, main.cpp:1263-1264)
+RT_HD float pixel_dx(const Camera &c, int i) { return c.X + i * c.s; }
+RT_HD float pixel_dy(const Camera &c, int j) { return c.Y - j * c.s; }
+RT_HD v3 primary_dir(const Camera &c, int mode, int m, float dx, float dy, int k, float &weight) {
     float s = c.s;
     if (mode == RT_MODE_REF_1SPP) {
-        float dx = c.X + i * s + s / 2;
-        float dy = c.Y - j * s + s / 2;
         weight = 1.0f;
-        return V3(dx, dy, 1);
+        return V3(dx + s / 2, dy + s / 2, 1);
     }
-    float dx = c.X + i * s, dy = c.Y - j * s;
     if (mode == RT_MODE_REF_AA9) {
         int kx = k % 3, ky = k / 3;
         float tx = dx + kx * s / 2;
@@ -1423,54 +1781,88 @@ RT_HD v3 primary_dir(const Camera &c, int mode, int m, int i, int j, int k, floa
 }
 // The same GRID tap from a table of the m offsets (grid_off[a] = grid_offset(a, m, s)) and the tap's column
 // and row: no integer division and no float division per tap.
-RT_HD v3 primary_dir_grid(const Camera &c, int i, int j, float off_x, float off_y) {
-    float s = c.s;
-    float dx = c.X + i * s, dy = c.Y - j * s;
-    return normalize(V3(dx + off_x, dy - off_y, 1));
-}
+RT_HD v3 primary_dir_grid(float dx, float dy, float off_x, float off_y) { return normalize(V3(dx + off_x, dy - off_y, 1)); }
 constexpr int kMaxGrid = 64;  // largest m of the GRID mode
 RT_HD void fill_grid_offsets(float *grid_off, int m, float s) {
     for (int a = 0; a < kMaxGrid; a++) grid_off[a] = a < m ? grid_offset(a, m, s) : 0.0f;
 }
-// toneMapping, main.cpp:1184-1189
+// toneMapping, main.cpp:1184-1189.  The result only feeds the 8-bit quantisation: on the GPU pow is exp2(g * log2(x))
+// with the hardware's 1-ulp functions (a few 1e-7 relative, i.e. 1 LSB off on about one pixel in ten thousand,
+// against some 250 instructions per call of the library's powf); 0 -> 0, negative and NaN -> NaN, inf -> inf as powf.
+RT_HD float tone_pow(float x, float g) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_exp2f(g * __builtin_amdgcn_logf(x));
+#else
+    return powf(x, g);
+#endif
+}
 RT_HD v3 tone_map(v3 c) {
     float gamma = (float)(1.0 / 1.8);
-    return V3(clamp01(18.0f * powf(c.x, gamma)), clamp01(18.0f * powf(c.y, gamma)), clamp01(18.0f * powf(c.z, gamma)));
+    return V3(clamp01(18.0f * tone_pow(c.x, gamma)), clamp01(18.0f * tone_pow(c.y, gamma)), clamp01(18.0f * tone_pow(c.z, gamma)));
 }
 // Image::setPixel(vec3), Image.cpp:35-39: int = (float)(255 * c), truncation
 RT_HD uint8_t quantise(float c) { return (uint8_t)(int)(float)(255 * c); }
 
-// One pixel: all taps in order, weighted sum, normalisation (main.cpp:1243-1270)
+// One pixel: all taps in order, weighted sum, normalisation (main.cpp:1243-1270).  The lanes of a wave walk their
+// taps in step: every lane calls next() alike, so the tap counters are wave-uniform (scalar registers), and a lane
+// whose pixel lies outside the frame (`inside` false) simply gets no ray.
+// PARKED: the pixel's corner and its running sum live in the Stack policy's per-lane storage (LDS columns on the
+// GPU) instead of registers: five values that are touched once per tap and would otherwise be held, or spilled to
+// scratch memory, through every traversal.
+constexpr int kTapSlots = 5;  // dx, dy, colour: after the cold_slots() columns of the kernel's feature set
+template <class Stack, bool PARKED, int BASE>
 struct PixelTaps {
+    enum : int { kColdTapDx = BASE, kColdTapDy = BASE + 1, kColdTapColor = BASE + 2 };
     Camera cam;
-    int mode, grid_m, taps, i, j, k;
+    int mode, grid_m, taps, k;
     int col, row;           // GRID: k = row * grid_m + col
     const float *grid_off;  // GRID: grid_offset(a, grid_m, cam.s) for a < grid_m
+    Stack *stk;
+    float dx, dy;           // the pixel's corner (not PARKED)
+    bool inside;
     float wt;
-    v3 color;
+    v3 color;               // (not PARKED)
+    RT_HD void start(float dx0, float dy0) {
+        if (PARKED) { stk->cold_put(kColdTapDx, dx0); stk->cold_put(kColdTapDy, dy0); cold_put3(*stk, kColdTapColor, V3(0, 0, 0)); }
+        else { dx = dx0; dy = dy0; color = V3(0, 0, 0); }
+    }
     RT_HD bool next(v3 &ro, v3 &rd) {
         if (k >= taps) return false;
         ro = V3(0, 0, 0);
+        const float x = PARKED ? stk->cold_get(kColdTapDx) : dx, y = PARKED ? stk->cold_get(kColdTapDy) : dy;
         if (mode == RT_MODE_GRID) {
-            rd = primary_dir_grid(cam, i, j, grid_off[col], grid_off[row]);
+            rd = primary_dir_grid(x, y, grid_off[col], grid_off[row]);
             wt = 1.0f;
             if (++col == grid_m) { col = 0; row++; }
         } else {
-            rd = primary_dir(cam, mode, grid_m, i, j, k, wt);
+            rd = primary_dir(cam, mode, grid_m, x, y, k, wt);
         }
         k++;
-        return true;
+        return inside;
     }
-    RT_HD void done(v3 r) { color = mode == RT_MODE_REF_1SPP ? r : color + r * wt; }
+    RT_HD void done(v3 r) {
+        if (PARKED) {
+            v3 c = cold_get3(*stk, kColdTapColor);
+            cold_put3(*stk, kColdTapColor, mode == RT_MODE_REF_1SPP ? r : c + r * wt);
+        } else {
+            color = mode == RT_MODE_REF_1SPP ? r : color + r * wt;
+        }
+    }
     RT_HD rt_hit_record *first_hit() { return nullptr; }
-    RT_HD v3 result() const { return mode == RT_MODE_REF_1SPP ? color : color / (mode == RT_MODE_REF_AA9 ? 16.f : (float)taps); }
+    RT_HD v3 result() {
+        v3 c = PARKED ? cold_get3(*stk, kColdTapColor) : color;
+        return mode == RT_MODE_REF_1SPP ? c : c / (mode == RT_MODE_REF_AA9 ? 16.f : (float)taps);
+    }
 };
-template <int F, bool COUNT, class Stack>
-RT_HD v3 render_pixel(const DevScene &S, const Camera &cam, int mode, int grid_m, int max_depth, int accel,
-                      int i, int j, const float *grid_off, Stack &stk, Work &wk) {
-    PixelTaps src;
+// inside: false for a lane without a pixel (it takes part in the wave's loop and traces nothing)
+template <int F, bool COUNT, bool PARKED, class Stack>
+RT_HD v3 render_pixel(SceneRef S, const Camera &cam, int mode, int grid_m, int max_depth, int accel,
+                      int i, int j, bool inside, const float *grid_off, Stack &stk, Work &wk) {
+    PixelTaps<Stack, PARKED, cold_slots(F)> src;
     src.cam = cam; src.mode = mode; src.grid_m = grid_m; src.taps = taps_of(mode, grid_m);
-    src.i = i; src.j = j; src.k = 0; src.col = 0; src.row = 0; src.grid_off = grid_off; src.wt = 1.0f; src.color = V3(0, 0, 0);
+    src.stk = &stk; src.inside = inside;
+    src.k = 0; src.col = 0; src.row = 0; src.grid_off = grid_off; src.wt = 1.0f;
+    src.start(pixel_dx(cam, i), pixel_dy(cam, j));
     trace_loop<F, COUNT>(S, max_depth, accel, stk, wk, src);
     return src.result();
 }

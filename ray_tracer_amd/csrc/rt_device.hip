@@ -72,9 +72,9 @@ struct WaveStack {
         mask = ((uint64_t)hi << 32) | lo;
     }
 };
-#define RT_WAVE_STACK(name, features)                                    \
+#define RT_WAVE_STACK(name, features, tap_slots)                         \
     __shared__ uint32_t name##_lds[kWavesPerBlock * kStackWords];        \
-    __shared__ float name##_cold[cold_slots(features) * kBlock];         \
+    __shared__ float name##_cold[(cold_slots(features) + ((tap_slots) ? kTapSlots : 0)) * kBlock]; \
     WaveStack name;                                                      \
     name.base = name##_lds + (threadIdx.x >> 6) * kStackWords;           \
     name.cold = name##_cold + threadIdx.x
@@ -389,16 +389,16 @@ __global__ void k_octant_variant0(BvhNode *nodes, int n) {
 }
 
 // One 16x16 tile by one block: each wave an 8x8 quadrant, each lane a pixel with all its taps.
-template <int F, bool COUNT>
-__device__ __forceinline__ void render_tile(const DevScene &S, const RenderArgs &a, int local, WaveStack &stk, const float *grid_off,
+template <int F, bool COUNT, bool PARKED>
+__device__ __forceinline__ void render_tile(SceneRef S, const RenderArgs &a, int local, WaveStack &stk, const float *grid_off,
                                             float *rgb_tiles, uint8_t *rgb8_tiles, Work &wk) {
     int tile = shard_tile(local, a.rank, a.world_size);
     int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     int px = (wave & 1) * 8 + (lane & 7), py = (wave >> 1) * 8 + (lane >> 3);
     int i = (tile % a.tiles_x) * RT_TILE_W + px, j = (tile / a.tiles_x) * RT_TILE_H + py;
-    v3 color = V3(0, 0, 0);
     bool inside = tile < a.tiles_total && i < a.width && j < a.height;
-    if (inside) color = render_pixel<F, COUNT>(S, a.cam, a.mode, a.grid_m, a.max_depth, a.accel, i, j, grid_off, stk, wk);
+    v3 color = render_pixel<F, COUNT, PARKED>(S, a.cam, a.mode, a.grid_m, a.max_depth, a.accel, i, j, inside, grid_off, stk, wk);
+    if (!inside) color = V3(0, 0, 0);
     size_t p = ((size_t)local * (RT_TILE_W * RT_TILE_H) + (size_t)py * RT_TILE_W + px) * 3;
     if (rgb_tiles) { rgb_tiles[p] = color.x; rgb_tiles[p + 1] = color.y; rgb_tiles[p + 2] = color.z; }
     if (rgb8_tiles) {
@@ -421,14 +421,15 @@ __device__ __forceinline__ void fill_grid_table(float *s_grid_off, const RenderA
 }
 
 template <int F, bool COUNT>
-__global__ __launch_bounds__(kBlock, render_waves(F, COUNT)) void k_render(DevScene S, RenderArgs a, float *rgb_tiles, uint8_t *rgb8_tiles,
+__global__ __launch_bounds__(kBlock, render_waves(F, COUNT)) void k_render(const DevScene *scene, RenderArgs a, float *rgb_tiles, uint8_t *rgb8_tiles,
                                                    unsigned long long *counters) {
-    RT_WAVE_STACK(stk, F);
+    SceneRef S = scene_ref(scene);
+    RT_WAVE_STACK(stk, F, true);
     __shared__ float s_grid_off[kMaxGrid];
     fill_grid_table(s_grid_off, a);
     Work wk;
     work_zero(wk);
-    render_tile<F, COUNT>(S, a, blockIdx.x, stk, s_grid_off, rgb_tiles, rgb8_tiles, wk);
+    render_tile<F, COUNT, true>(S, a, blockIdx.x, stk, s_grid_off, rgb_tiles, rgb8_tiles, wk);
     flush_work(wk, counters, COUNT);
 }
 
@@ -442,7 +443,9 @@ __global__ __launch_bounds__(kBlock, render_waves(F, COUNT)) void k_render(DevSc
 constexpr int kRoundTaps = 8;
 struct TapSlice {  // a trace_loop source: taps [k, k_end) of one pixel
     Camera cam;
-    int mode, grid_m, i, j, k, k_end, base;
+    int mode, grid_m, k, k_end, base;
+    float dx, dy;           // the pixel's corner (pixel_dx, pixel_dy)
+    bool inside;            // the lane has a pixel of the frame and taps of its own in this round
     int col, row;           // GRID: k = row * grid_m + col
     const float *grid_off;  // GRID: the block's table of grid_offset(a, grid_m, cam.s)
     float wt;
@@ -453,14 +456,14 @@ struct TapSlice {  // a trace_loop source: taps [k, k_end) of one pixel
         if (k >= k_end) return false;
         ro = V3(0, 0, 0);
         if (mode == RT_MODE_GRID) {
-            rd = primary_dir_grid(cam, i, j, grid_off[col], grid_off[row]);
+            rd = primary_dir_grid(dx, dy, grid_off[col], grid_off[row]);
             wt = 1.0f;
             if (++col == grid_m) { col = 0; row++; }
         } else {
-            rd = primary_dir(cam, mode, grid_m, i, j, k, wt);
+            rd = primary_dir(cam, mode, grid_m, dx, dy, k, wt);
         }
         k++;
-        return true;
+        return inside;
     }
     __device__ void done(v3 r) {
         if (slots == nullptr) {  // (wave-uniform)
@@ -478,7 +481,7 @@ struct TapSlice {  // a trace_loop source: taps [k, k_end) of one pixel
 // taps finish.  part = 0..3: that quadrant alone, the taps of its pixels spread over the four waves in rounds of
 // kRoundTaps and summed in tap order through LDS (tap_lds: kRoundTaps * 3 * 64 floats), as render_tile_part does.
 template <int F>
-__device__ __forceinline__ void render_item(const DevScene &S, const RenderArgs &a, int local, int part, WaveStack &stk, const float *grid_off,
+__device__ __forceinline__ void render_item(SceneRef S, const RenderArgs &a, int local, int part, WaveStack &stk, const float *grid_off,
                                             float *tap_lds, float *rgb_tiles, uint8_t *rgb8_tiles, Work &wk) {
     const bool whole = part < 0;  // (block-uniform)
     const int tile = shard_tile(local, a.rank, a.world_size);
@@ -494,14 +497,15 @@ __device__ __forceinline__ void render_item(const DevScene &S, const RenderArgs 
         const int n = taps - base < round_taps ? taps - base : round_taps;
         const int chunk = whole ? n : (n + 3) / 4, slot = whole ? 0 : wave;
         TapSlice src;
-        src.cam = a.cam; src.mode = a.mode; src.grid_m = a.grid_m; src.i = i; src.j = j; src.base = base; src.wt = 1.0f;
+        src.cam = a.cam; src.mode = a.mode; src.grid_m = a.grid_m; src.dx = pixel_dx(a.cam, i); src.dy = pixel_dy(a.cam, j); src.base = base; src.wt = 1.0f;
         src.k = base + (slot * chunk < n ? slot * chunk : n);
         src.k_end = base + ((slot + 1) * chunk < n ? (slot + 1) * chunk : n);
         src.col = src.k % a.grid_m; src.row = src.k / a.grid_m; src.grid_off = grid_off;
         src.slots = whole ? nullptr : tap_lds + lane;
         src.stride = 64;
         src.color = color;
-        if (inside && src.k < src.k_end) trace_loop<F, false>(S, a.max_depth, a.accel, stk, wk, src);
+        src.inside = inside;
+        trace_loop<F, false>(S, a.max_depth, a.accel, stk, wk, src);
         color = src.color;
         if (!whole) {
             __syncthreads();
@@ -530,7 +534,7 @@ __device__ __forceinline__ void render_item(const DevScene &S, const RenderArgs 
 
 // Part `part` (of 4 * PH) of local tile `local` by one block; tap_lds: kRoundTaps * 3 * (64 / PH) floats of LDS.
 template <int F, bool COUNT, int PH>
-__device__ __forceinline__ void render_tile_part(const DevScene &S, const RenderArgs &a, int local, int part, WaveStack &stk,
+__device__ __forceinline__ void render_tile_part(SceneRef S, const RenderArgs &a, int local, int part, WaveStack &stk,
                                                  const float *grid_off, float *tap_lds, float *rgb_tiles, uint8_t *rgb8_tiles, Work &wk) {
     constexpr int PX = 64 / PH;  // pixels of a block
     const int quad = part / PH, sub = part % PH;
@@ -547,14 +551,15 @@ __device__ __forceinline__ void render_tile_part(const DevScene &S, const Render
     for (int base = 0; base < taps; base += kRoundTaps) {
         int n = taps - base < kRoundTaps ? taps - base : kRoundTaps, chunk = (n + 4 * PH - 1) / (4 * PH);
         TapSlice src;
-        src.cam = a.cam; src.mode = a.mode; src.grid_m = a.grid_m; src.i = i; src.j = j; src.base = base; src.wt = 1.0f;
+        src.cam = a.cam; src.mode = a.mode; src.grid_m = a.grid_m; src.dx = pixel_dx(a.cam, i); src.dy = pixel_dy(a.cam, j); src.base = base; src.wt = 1.0f;
         src.k = base + (slot * chunk < n ? slot * chunk : n);
         src.k_end = base + ((slot + 1) * chunk < n ? (slot + 1) * chunk : n);
         src.col = src.k % a.grid_m; src.row = src.k / a.grid_m; src.grid_off = grid_off;  // (one division per round, not per tap)
         src.slots = tap_lds + pl;
         src.stride = PX;
         src.color = V3(0, 0, 0);
-        if (inside && src.k < src.k_end) trace_loop<F, COUNT>(S, a.max_depth, a.accel, stk, wk, src);
+        src.inside = inside;
+        trace_loop<F, COUNT>(S, a.max_depth, a.accel, stk, wk, src);
         __syncthreads();
         if (wave == 0 && phase == 0 && inside) {
             for (int t = 0; t < n; t++) {
@@ -579,10 +584,11 @@ __device__ __forceinline__ void render_tile_part(const DevScene &S, const Render
 }
 
 template <int F, bool COUNT, int PH>
-__global__ __launch_bounds__(kBlock, split_waves(F, COUNT)) void k_render_split(DevScene S, RenderArgs a, float *rgb_tiles,
+__global__ __launch_bounds__(kBlock, split_waves(F, COUNT)) void k_render_split(const DevScene *scene, RenderArgs a, float *rgb_tiles,
                                                                                  uint8_t *rgb8_tiles, unsigned long long *counters) {
+    SceneRef S = scene_ref(scene);
     unbundle(a);
-    RT_WAVE_STACK(stk, F);
+    RT_WAVE_STACK(stk, F, false);
     __shared__ float tap_lds[kRoundTaps * 3 * (64 / PH)];
     __shared__ float s_grid_off[kMaxGrid];
     fill_grid_table(s_grid_off, a);
@@ -600,9 +606,10 @@ __global__ __launch_bounds__(kBlock, split_waves(F, COUNT)) void k_render_split(
 // cost_out (another array than cost_in: the four blocks of a tile must read the same value).
 struct TileCosts { const uint32_t *cost_in; uint32_t *cost_out; const uint32_t *threshold; };  // threshold: written by k_tile_threshold just before
 template <int F>
-__global__ __launch_bounds__(kBlock, split_waves(F, false)) void k_render_hybrid(DevScene S, RenderArgs a, float *rgb_tiles,
+__global__ __launch_bounds__(kBlock, split_waves(F, false)) void k_render_hybrid(const DevScene *scene, RenderArgs a, float *rgb_tiles,
                                                                                   uint8_t *rgb8_tiles, unsigned long long *counters,
                                                                                   TileCosts tc) {
+    SceneRef S = scene_ref(scene);
     const int local = blockIdx.x >> 2, quad = blockIdx.x & 3;
     const bool heavy = tc.cost_in[local] > *tc.threshold;  // the same for the tile's four blocks
     // Which of the four blocks takes a light tile is scattered by a hash of the tile: blocks are handed to the
@@ -612,14 +619,14 @@ __global__ __launch_bounds__(kBlock, split_waves(F, false)) void k_render_hybrid
     if (!heavy && quad != worker) return;
     const unsigned long long t0 = wall_clock64();
     unbundle(a);
-    RT_WAVE_STACK(stk, F);
+    RT_WAVE_STACK(stk, F, false);
     __shared__ float tap_lds[kRoundTaps * 3 * 64];
     __shared__ float s_grid_off[kMaxGrid];
     fill_grid_table(s_grid_off, a);
     Work wk;
     work_zero(wk);
     if (heavy) render_tile_part<F, false, 1>(S, a, local, quad, stk, s_grid_off, tap_lds, rgb_tiles, rgb8_tiles, wk);
-    else render_tile<F, false>(S, a, local, stk, s_grid_off, rgb_tiles, rgb8_tiles, wk);
+    else render_tile<F, false, false>(S, a, local, stk, s_grid_off, rgb_tiles, rgb8_tiles, wk);
     flush_work(wk, counters, false);
     __syncthreads();
     if (threadIdx.x == 0 && quad == worker) {
@@ -744,15 +751,16 @@ __global__ __launch_bounds__(kPlanThreads) void k_plan_tiles(QueueHeader *q, con
 // cannot touch the tables does it keep fetching them through the scalar cache.)
 struct QueueArgs { QueueHeader *q; const uint32_t *items; uint32_t *cost_out; };
 template <int F>
-__global__ __launch_bounds__(kBlock, split_waves(F, false)) void k_render_queue(DevScene S, RenderArgs a, float *__restrict__ rgb_tiles,
+__global__ __launch_bounds__(kBlock, split_waves(F, false)) void k_render_queue(const DevScene *scene, RenderArgs a, float *__restrict__ rgb_tiles,
                                                                                  uint8_t *__restrict__ rgb8_tiles,
                                                                                  unsigned long long *__restrict__ counters,
                                                                                  QueueHeader *__restrict__ q_hdr,
                                                                                  const uint32_t *__restrict__ q_items,
                                                                                  uint32_t *__restrict__ q_cost_out) {
+    SceneRef S = scene_ref(scene);
     QueueArgs qa = {q_hdr, q_items, q_cost_out};
     unbundle(a);
-    RT_WAVE_STACK(stk, F);
+    RT_WAVE_STACK(stk, F, false);
     __shared__ float tap_lds[kRoundTaps * 3 * 64];
     __shared__ float s_grid_off[kMaxGrid];
     __shared__ uint32_t s_item;
@@ -820,10 +828,11 @@ static void untile_launch_shape(size_t tiles, const T *shards, const T *frame, i
            ((size_t)width * 3 * sizeof(T)) % 16 == 0) ? 1 : 0;
 }
 
-__global__ __launch_bounds__(kBlock) void k_trace_rays(DevScene S, long long n, const float *o, const float *d,
+__global__ __launch_bounds__(kBlock) void k_trace_rays(const DevScene *scene, long long n, const float *o, const float *d,
                                                        int max_depth, int accel, rt_hit_record *hits, float *radiance,
                                                        unsigned long long *counters) {
-    RT_WAVE_STACK(stk, F_ALL);
+    SceneRef S = scene_ref(scene);
+    RT_WAVE_STACK(stk, F_ALL, false);
     long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     Work wk;
     work_zero(wk);
@@ -836,9 +845,10 @@ __global__ __launch_bounds__(kBlock) void k_trace_rays(DevScene S, long long n, 
     flush_work(wk, counters, false);
 }
 
-__global__ __launch_bounds__(kBlock) void k_intersect_object(DevScene S, int object, long long n, const float *o,
+__global__ __launch_bounds__(kBlock) void k_intersect_object(const DevScene *scene, int object, long long n, const float *o,
                                                              const float *d, int accel, rt_hit_record *hits) {
-    RT_WAVE_STACK(stk, F_ALL);
+    SceneRef S = scene_ref(scene);
+    RT_WAVE_STACK(stk, F_ALL, false);
     long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n) return;
     Work wk;
@@ -873,11 +883,13 @@ struct rt_ctx {
     std::string err;
     bool uploaded = false, built = false;
     std::vector<void *> allocs;  // everything owned by the current scene
-    DevScene S{};
+    DevScene S{};                 // the scene record as the host fills it
+    DevScene *d_scene = nullptr;  // its copy in device memory: what the kernels read
     std::vector<DevMesh> meshes;
     std::vector<MeshBuild> mesh_build;
     int n_triangles = 0, n_meshes = 0, n_nodes = 0, n_textures = 0, n_materials = 0;
     std::vector<int32_t> mesh_ranges;  // (tri_offset, tri_count) of every uploaded mesh
+    std::vector<const void *> tex_addr;  // device address of every texture's texel records (nullptr: procedural)
     // device arrays the build writes
     float *d_tri_pos = nullptr;
     float *d_ref_pos = nullptr;    // 9 floats per reference (a piece of a triangle), in cutting order
@@ -941,6 +953,7 @@ static void free_scene(rt_ctx *ctx) {
     ctx->meshes.clear();
     ctx->mesh_build.clear();
     ctx->S = DevScene{};
+    ctx->d_scene = nullptr;
 }
 
 static int noalloc_setup(rt_ctx *ctx);  // (below, next to the static tile memory)
@@ -1023,14 +1036,12 @@ extern "C" int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *sc) {
 
     int rc;
     rt_object *d_objects; rt_sphere *d_spheres; rt_plane *d_planes; rt_cone *d_cones; rt_material *d_materials;
-    float *d_lp, *d_lc, *d_nrm, *d_uv; int32_t *d_tmat;
+    float *d_nrm, *d_uv; int32_t *d_tmat;
     if ((rc = dev_alloc(ctx, &d_objects, sc->n_objects, sc->objects))) return rc;
     if ((rc = dev_alloc(ctx, &d_spheres, sc->n_spheres, sc->spheres))) return rc;
     if ((rc = dev_alloc(ctx, &d_planes, sc->n_planes, sc->planes))) return rc;
     if ((rc = dev_alloc(ctx, &d_cones, sc->n_cones, sc->cones))) return rc;
     if ((rc = dev_alloc(ctx, &d_materials, sc->n_materials, sc->materials))) return rc;
-    if ((rc = dev_alloc(ctx, &d_lp, 3 * (size_t)sc->n_lights, sc->light_pos))) return rc;
-    if ((rc = dev_alloc(ctx, &d_lc, 3 * (size_t)sc->n_lights, sc->light_color))) return rc;
     size_t nt = sc->n_triangles;
     if ((rc = dev_alloc(ctx, &ctx->d_tri_pos, 9 * nt, sc->tri_pos))) return rc;
     if ((rc = dev_alloc(ctx, &d_nrm, 9 * nt, sc->tri_nrm))) return rc;
@@ -1070,18 +1081,29 @@ extern "C" int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *sc) {
     if ((rc = dev_alloc(ctx, &d_plane_obj, plane_obj.size(), plane_obj.data()))) return rc;
     if ((rc = dev_alloc(ctx, &d_sphere_cull, sphere_cull.size(), sphere_cull.data()))) return rc;
     if ((rc = dev_alloc(ctx, &d_cone_obj, cone_obj.size(), cone_obj.data()))) return rc;
-    std::vector<AxisPlaneRec> axis_planes;
+    std::vector<AxisPair> axis_pairs;
     std::vector<PlaneRec> gen_planes;
-    make_plane_recs(sc, plane_obj, axis_planes, gen_planes);
-    AxisPlaneRec *d_axis_planes;
+    const uint32_t planes_skip_lights = make_plane_recs(sc, plane_obj, axis_pairs, gen_planes);
+    AxisPair *d_axis_overflow;
     PlaneRec *d_gen_planes;
     // sized for any split of the planes into the two classes, so that rt_scene_update can re-partition them
-    size_t cap_axis = ((size_t)sc->n_planes + kAxisPlaneGroup - 1) / kAxisPlaneGroup * kAxisPlaneGroup;
-    size_t cap_gen = ((size_t)sc->n_planes + kPlaneGroup - 1) / kPlaneGroup * kPlaneGroup;
-    if ((rc = dev_alloc(ctx, &d_axis_planes, cap_axis, (const void *)nullptr))) return rc;
-    if ((rc = dev_alloc(ctx, &d_gen_planes, cap_gen, (const void *)nullptr))) return rc;
-    if (!axis_planes.empty()) RT_HIP(hipMemcpyAsync(d_axis_planes, axis_planes.data(), axis_planes.size() * sizeof(AxisPlaneRec), hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = dev_alloc(ctx, &d_axis_overflow, axis_pair_capacity(sc->n_planes), (const void *)nullptr))) return rc;
+    if ((rc = dev_alloc(ctx, &d_gen_planes, gen_plane_capacity(sc->n_planes), (const void *)nullptr))) return rc;
+    if (axis_pairs.size() > (size_t)kFixedAxisPairs)
+        RT_HIP(hipMemcpyAsync(d_axis_overflow, axis_pairs.data() + kFixedAxisPairs, (axis_pairs.size() - kFixedAxisPairs) * sizeof(AxisPair),
+                              hipMemcpyHostToDevice, ctx->stream));
     if (!gen_planes.empty()) RT_HIP(hipMemcpyAsync(d_gen_planes, gen_planes.data(), gen_planes.size() * sizeof(PlaneRec), hipMemcpyHostToDevice, ctx->stream));
+    // the materials and objects as shading reads them
+    ctx->tex_addr.assign(sc->n_textures, nullptr);
+    for (int i = 0; i < sc->n_textures; i++) ctx->tex_addr[i] = tex[i].texels;
+    std::vector<MatRec> mat_recs;
+    std::vector<ObjRec> obj_recs;
+    make_mat_recs(sc, ctx->tex_addr, mat_recs);
+    make_obj_recs(sc, mat_recs, obj_recs);
+    MatRec *d_mat_recs;
+    ObjRec *d_obj_recs;
+    if ((rc = dev_alloc(ctx, &d_mat_recs, mat_recs.size(), mat_recs.data()))) return rc;
+    if ((rc = dev_alloc(ctx, &d_obj_recs, obj_recs.size(), obj_recs.data()))) return rc;
 
     // meshes: bounds, padding, gate triangles, node ranges
     ctx->n_meshes = sc->n_meshes;
@@ -1103,9 +1125,11 @@ extern "C" int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *sc) {
     f4 *d_gate;
     if ((rc = dev_alloc(ctx, &d_gate, gate.size(), gate.data()))) return rc;
     std::vector<LightCull> cull;
-    uint32_t cullable = make_light_cull(sc, ctx->meshes, axis_planes, gen_planes, cull);
-    LightCull *d_cull;
-    if ((rc = dev_alloc(ctx, &d_cull, cull.size(), cull.data()))) return rc;
+    uint32_t cullable = make_light_cull(sc, ctx->meshes, planes_skip_lights, cull);
+    std::vector<LightRec> light_recs;
+    make_light_recs(sc, cull, light_recs);
+    LightRec *d_light_recs;
+    if ((rc = dev_alloc(ctx, &d_light_recs, light_recs.size(), light_recs.data()))) return rc;
     if ((rc = dev_alloc(ctx, &ctx->d_nodes, (size_t)node_total, (const void *)nullptr))) return rc;
     if ((rc = dev_alloc(ctx, &ctx->d_meshes, ctx->meshes.size(), ctx->meshes.data()))) return rc;
 
@@ -1122,15 +1146,16 @@ extern "C" int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *sc) {
     DevScene &S = ctx->S;
     S.n_objects = sc->n_objects; S.n_lights = sc->n_lights;
     S.n_planes = sc->n_planes; S.n_spheres = sc->n_spheres; S.n_cones = sc->n_cones; S.n_meshes = sc->n_meshes;
-    S.n_axis_planes = (int32_t)axis_planes.size(); S.n_gen_planes = (int32_t)gen_planes.size();
-    S.axis_planes = d_axis_planes; S.gen_planes = d_gen_planes;
+    S.n_axis_overflow = (int32_t)axis_pairs.size() - kFixedAxisPairs; S.n_gen_planes = (int32_t)gen_planes.size();
+    S.axis_overflow = d_axis_overflow; S.gen_planes = d_gen_planes; S.planes_skip_lights = planes_skip_lights;
+    S.obj_recs = d_obj_recs; S.mat_recs = d_mat_recs;
     S.plane_obj = d_plane_obj; S.sphere_cull = d_sphere_cull; S.cone_obj = d_cone_obj;
     S.objects = d_objects; S.spheres = d_spheres; S.planes = d_planes; S.cones = d_cones; S.meshes = ctx->d_meshes;
     S.tri_test = ctx->d_tri_test; S.tri_key = ctx->d_tri_key; S.tri_orig = ctx->d_tri_orig;
     S.tri_nrm = d_nrm; S.tri_uv = d_uv; S.tri_material = d_tmat; S.tri_frag = ctx->d_tri_frag; S.tri_sub = ctx->d_tri_sub;
-    S.gate_tri = d_gate; S.light_cull = d_cull; S.cullable_lights = cullable; S.gate_entry_first = (scene_features(sc) & F_SECONDARY) ? 1 : 0; S.nodes = ctx->d_nodes; S.materials = d_materials; S.textures = d_tex; S.srgb_lut = d_lut;
-    S.light_pos = d_lp; S.light_color = d_lc;
-    for (int a = 0; a < 3; a++) S.ambient[a] = sc->ambient[a];
+    S.gate_tri = d_gate; S.light_recs = d_light_recs; S.cullable_lights = cullable; S.gate_entry_first = (scene_features(sc) & F_SECONDARY) ? 1 : 0; S.nodes = ctx->d_nodes; S.materials = d_materials; S.textures = d_tex; S.srgb_lut = d_lut;
+    fill_embedded(S, axis_pairs, gen_planes, ctx->meshes, obj_recs, light_recs);
+    if ((rc = dev_alloc(ctx, &ctx->d_scene, 1, &S))) return rc;
     RT_HIP(hipStreamSynchronize(ctx->stream));  // the caller's arrays may go away after return
     ctx->features = scene_features(sc);
     ctx->uploaded = true;
@@ -1169,7 +1194,8 @@ extern "C" int rt_scene_update(rt_ctx *ctx, const rt_scene_desc *sc) {
     if ((rc = dev_update(ctx, S.spheres, sc->spheres, sc->n_spheres))) return rc;
     if ((rc = dev_update(ctx, S.planes, sc->planes, sc->n_planes))) return rc;
     if ((rc = dev_update(ctx, S.cones, sc->cones, sc->n_cones))) return rc;
-    if (sc->n_materials > ctx->n_materials) {  // more distinct materials than the table holds: a larger table
+    const bool grown_materials = sc->n_materials > ctx->n_materials;
+    if (grown_materials) {  // more distinct materials than the table holds: a larger table
         rt_material *d_materials;
         if ((rc = dev_alloc(ctx, &d_materials, sc->n_materials, (const void *)nullptr))) return rc;
         S.materials = d_materials;
@@ -1177,8 +1203,6 @@ extern "C" int rt_scene_update(rt_ctx *ctx, const rt_scene_desc *sc) {
     }
     if ((rc = dev_update(ctx, S.materials, sc->materials, sc->n_materials))) return rc;
     if ((rc = dev_update(ctx, S.tri_material, sc->tri_material, (size_t)sc->n_triangles))) return rc;  // indices into the new table
-    if ((rc = dev_update(ctx, S.light_pos, sc->light_pos, 3 * (size_t)sc->n_lights))) return rc;
-    if ((rc = dev_update(ctx, S.light_color, sc->light_color, 3 * (size_t)sc->n_lights))) return rc;
     std::vector<int32_t> plane_obj, sphere_obj, cone_obj, mesh_obj;
     kind_to_object(sc, plane_obj, sphere_obj, cone_obj, mesh_obj);
     if ((rc = dev_update(ctx, S.plane_obj, plane_obj.data(), plane_obj.size()))) return rc;
@@ -1186,12 +1210,23 @@ extern "C" int rt_scene_update(rt_ctx *ctx, const rt_scene_desc *sc) {
     sphere_culls(sc, sphere_obj, sphere_cull);
     if ((rc = dev_update(ctx, S.sphere_cull, sphere_cull.data(), sphere_cull.size()))) return rc;
     if ((rc = dev_update(ctx, S.cone_obj, cone_obj.data(), cone_obj.size()))) return rc;
-    std::vector<AxisPlaneRec> axis_planes;
+    std::vector<AxisPair> axis_pairs;
     std::vector<PlaneRec> gen_planes;
-    make_plane_recs(sc, plane_obj, axis_planes, gen_planes);
-    if ((rc = dev_update(ctx, S.axis_planes, axis_planes.data(), axis_planes.size()))) return rc;
+    S.planes_skip_lights = make_plane_recs(sc, plane_obj, axis_pairs, gen_planes);
+    if ((rc = dev_update(ctx, S.axis_overflow, axis_pairs.data() + kFixedAxisPairs, axis_pairs.size() - kFixedAxisPairs))) return rc;
     if ((rc = dev_update(ctx, S.gen_planes, gen_planes.data(), gen_planes.size()))) return rc;
-    S.n_axis_planes = (int32_t)axis_planes.size(); S.n_gen_planes = (int32_t)gen_planes.size();
+    S.n_axis_overflow = (int32_t)axis_pairs.size() - kFixedAxisPairs; S.n_gen_planes = (int32_t)gen_planes.size();
+    std::vector<MatRec> mat_recs;
+    std::vector<ObjRec> obj_recs;
+    make_mat_recs(sc, ctx->tex_addr, mat_recs);
+    make_obj_recs(sc, mat_recs, obj_recs);
+    if (grown_materials) {
+        MatRec *d_mat_recs;
+        if ((rc = dev_alloc(ctx, &d_mat_recs, mat_recs.size(), (const void *)nullptr))) return rc;
+        S.mat_recs = d_mat_recs;
+    }
+    if ((rc = dev_update(ctx, S.mat_recs, mat_recs.data(), mat_recs.size()))) return rc;
+    if ((rc = dev_update(ctx, S.obj_recs, obj_recs.data(), obj_recs.size()))) return rc;
     // mesh records: new maps, gate boxes and world bounds; triangle and node ranges are unchanged
     std::vector<DevMesh> meshes;
     std::vector<MeshBuild> build = ctx->mesh_build;  // the reference ranges stay
@@ -1206,13 +1241,16 @@ extern "C" int rt_scene_update(rt_ctx *ctx, const rt_scene_desc *sc) {
     ctx->meshes = meshes;
     if ((rc = dev_update(ctx, S.gate_tri, gate.data(), gate.size()))) return rc;
     std::vector<LightCull> cull;
-    S.cullable_lights = make_light_cull(sc, ctx->meshes, axis_planes, gen_planes, cull);
-    if ((rc = dev_update(ctx, S.light_cull, cull.data(), cull.size()))) return rc;
+    S.cullable_lights = make_light_cull(sc, ctx->meshes, S.planes_skip_lights, cull);
+    std::vector<LightRec> light_recs;
+    make_light_recs(sc, cull, light_recs);
+    if ((rc = dev_update(ctx, S.light_recs, light_recs.data(), light_recs.size()))) return rc;
     if ((rc = dev_update(ctx, S.meshes, ctx->meshes.data(), ctx->meshes.size()))) return rc;
-    for (int a = 0; a < 3; a++) S.ambient[a] = sc->ambient[a];
-    RT_HIP(hipStreamSynchronize(ctx->stream));  // the caller's arrays may go away after return
+    fill_embedded(S, axis_pairs, gen_planes, ctx->meshes, obj_recs, light_recs);
     ctx->features = scene_features(sc);
     S.gate_entry_first = (ctx->features & F_SECONDARY) ? 1 : 0;
+    RT_HIP(hipMemcpyAsync(ctx->d_scene, &S, sizeof S, hipMemcpyHostToDevice, ctx->stream));
+    RT_HIP(hipStreamSynchronize(ctx->stream));  // the caller's arrays may go away after return
     return RT_OK;
 }
 
@@ -1340,6 +1378,8 @@ extern "C" int rt_build_accel(rt_ctx *ctx) {
     for (size_t i = 0; i < n_meshes; i++) { ctx->mesh_build[i].root = root_ids[i]; ctx->meshes[i].root = root_ids[i]; }
     if (e == hipSuccess)  // the roots
         e = hipMemcpy(ctx->d_meshes, ctx->meshes.data(), n_meshes * sizeof(DevMesh), hipMemcpyHostToDevice);
+    for (size_t i = 0; i < n_meshes && i < (size_t)kEmbMeshes; i++) ctx->S.mesh_heads[i] = ctx->meshes[i];  // (the copies in the scene record)
+    if (e == hipSuccess) e = hipMemcpy(ctx->d_scene, &ctx->S, sizeof ctx->S, hipMemcpyHostToDevice);
     cleanup();
     if (e != hipSuccess) return fail(ctx, RT_ERR_HIP, std::string("tree build: ") + hipGetErrorString(e));
     if (unfinished) return fail(ctx, RT_ERR_LIMIT, "tree build: levels left over");
@@ -1493,54 +1533,60 @@ static int render_shard(rt_ctx *ctx, const rt_render_params *p, float *d_rgb_til
     const uint32_t forced_threshold = ctx->forced_threshold >= 0 ? (uint32_t)std::min<long long>(ctx->forced_threshold, 0xfffffffell) : 0u;
     const int use_forced = ctx->forced_threshold >= 0 ? 1 : 0;
     if (variant == kVariantQueue) {
-        typedef void (*queue_fn)(DevScene, RenderArgs, float *, uint8_t *, unsigned long long *, QueueHeader *, const uint32_t *, uint32_t *);
+        typedef void (*queue_fn)(const DevScene *, RenderArgs, float *, uint8_t *, unsigned long long *, QueueHeader *, const uint32_t *, uint32_t *);
         queue_fn kernel;
         int slots;
 #define RT_QUEUE(FEATURES) (kernel = k_render_queue<FEATURES>, slots = queue_slots_of<FEATURES>(ctx))
-        if (f == 0) RT_QUEUE(0);
-        else if ((f & ~F_MESH) == 0) RT_QUEUE(F_MESH);
+        if ((f & ~F_MESH) == 0) RT_QUEUE(F_MESH);
+#ifndef RT_LEAN_BUILD
+        else if (f == 0) RT_QUEUE(0);
         else if ((f & ~(F_MESH | F_SECONDARY)) == 0) RT_QUEUE(F_MESH | F_SECONDARY);
         else if ((f & ~(F_QUADRIC | F_SECONDARY)) == 0) RT_QUEUE(F_QUADRIC | F_SECONDARY);
         else if ((f & ~(F_QUADRIC | F_TEXTURE | F_SECONDARY)) == 0) RT_QUEUE(F_QUADRIC | F_TEXTURE | F_SECONDARY);
         else if ((f & ~(F_MESH | F_TEXTURE | F_SECONDARY)) == 0) RT_QUEUE(F_MESH | F_TEXTURE | F_SECONDARY);
+#endif
         else RT_QUEUE(F_ALL);
 #undef RT_QUEUE
         const int blocks = std::min(slots, 4 * local_tiles);
         hipLaunchKernelGGL(k_plan_tiles, dim3(1), dim3(kPlanThreads), 0, ctx->stream, tm.hdr, tm.cost[tm.turn], tm.cost[tm.turn ^ 1], tm.items,
                            local_tiles, blocks, forced_threshold, use_forced);
-        hipLaunchKernelGGL(kernel, dim3(blocks), dim3(kBlock), 0, ctx->stream, ctx->S, a, d_rgb_tiles, d_rgb8_tiles, ctx->d_counters, tm.hdr,
+        hipLaunchKernelGGL(kernel, dim3(blocks), dim3(kBlock), 0, ctx->stream, ctx->d_scene, a, d_rgb_tiles, d_rgb8_tiles, ctx->d_counters, tm.hdr,
                            (const uint32_t *)tm.items, tm.cost[tm.turn ^ 1]);
         tm.turn ^= 1;
     } else if (variant == 3) {
-        typedef void (*hybrid_fn)(DevScene, RenderArgs, float *, uint8_t *, unsigned long long *, TileCosts);
+        typedef void (*hybrid_fn)(const DevScene *, RenderArgs, float *, uint8_t *, unsigned long long *, TileCosts);
         hybrid_fn hk = k_render_hybrid<F_ALL>;
         if ((f & ~F_MESH) == 0) hk = k_render_hybrid<F_MESH>;
+#ifndef RT_LEAN_BUILD
         else if ((f & ~(F_MESH | F_SECONDARY)) == 0) hk = k_render_hybrid<F_MESH | F_SECONDARY>;
         else if ((f & ~(F_MESH | F_TEXTURE | F_SECONDARY)) == 0) hk = k_render_hybrid<F_MESH | F_TEXTURE | F_SECONDARY>;
+#endif
         // a tile is heavy when it took more than 1.5 times the average tile: the threshold is formed on the device
         // from last frame's times, so that no frame waits for the host to look at them
         hipLaunchKernelGGL(k_tile_threshold, dim3(1), dim3(kPlanThreads), 0, ctx->stream, tm.hdr, (const uint32_t *)tm.cost[tm.turn], local_tiles,
                            forced_threshold, use_forced);
         TileCosts tc = {tm.cost[tm.turn], tm.cost[tm.turn ^ 1], &tm.hdr->threshold};
-        hipLaunchKernelGGL(hk, dim3(4 * local_tiles), dim3(kBlock), 0, ctx->stream, ctx->S, a, d_rgb_tiles, d_rgb8_tiles, ctx->d_counters, tc);
+        hipLaunchKernelGGL(hk, dim3(4 * local_tiles), dim3(kBlock), 0, ctx->stream, ctx->d_scene, a, d_rgb_tiles, d_rgb8_tiles, ctx->d_counters, tc);
         tm.turn ^= 1;
     } else {
-        typedef void (*render_fn)(DevScene, RenderArgs, float *, uint8_t *, unsigned long long *);
+        typedef void (*render_fn)(const DevScene *, RenderArgs, float *, uint8_t *, unsigned long long *);
         render_fn kernel;
 #define RT_PICK(FEATURES, COUNT)                                                              \
     (variant == 0 ? (render_fn)k_render<FEATURES, COUNT>                                      \
                   : variant == 1 ? (render_fn)k_render_split<FEATURES, COUNT, 1> : (render_fn)k_render_split<FEATURES, COUNT, 2>)
         if (p->count_work) kernel = (render_fn)k_render<F_ALL, true>;
-        else if (f == 0) kernel = RT_PICK(0, false);
         else if ((f & ~F_MESH) == 0) kernel = RT_PICK(F_MESH, false);
+#ifndef RT_LEAN_BUILD  // (a developer's build with -DRT_LEAN_BUILD has the mesh-only and the all-features kernels alone: a quarter of the compile time)
+        else if (f == 0) kernel = RT_PICK(0, false);
         else if ((f & ~(F_MESH | F_SECONDARY)) == 0) kernel = RT_PICK(F_MESH | F_SECONDARY, false);
         else if ((f & ~(F_QUADRIC | F_SECONDARY)) == 0) kernel = RT_PICK(F_QUADRIC | F_SECONDARY, false);
         else if ((f & ~(F_QUADRIC | F_TEXTURE | F_SECONDARY)) == 0) kernel = RT_PICK(F_QUADRIC | F_TEXTURE | F_SECONDARY, false);
         else if ((f & ~(F_MESH | F_TEXTURE | F_SECONDARY)) == 0) kernel = RT_PICK(F_MESH | F_TEXTURE | F_SECONDARY, false);
+#endif
         else kernel = RT_PICK(F_ALL, false);
 #undef RT_PICK
         const int blocks_per_tile = variant == 0 ? 1 : variant == 2 ? 8 : 4;
-        hipLaunchKernelGGL(kernel, dim3(blocks_per_tile * local_tiles), dim3(kBlock), 0, ctx->stream, ctx->S, a, d_rgb_tiles, d_rgb8_tiles,
+        hipLaunchKernelGGL(kernel, dim3(blocks_per_tile * local_tiles), dim3(kBlock), 0, ctx->stream, ctx->d_scene, a, d_rgb_tiles, d_rgb8_tiles,
                            ctx->d_counters);
     }
     RT_HIP(hipGetLastError());
@@ -1683,7 +1729,7 @@ extern "C" int rt_trace_rays(rt_ctx *ctx, int64_t n, const float *o, const float
     if (e == hipSuccess) e = hipMemcpyAsync(d_o, o, 3 * n * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d_d, d, 3 * n * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_trace_rays, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, ctx->S, (long long)n,
+        hipLaunchKernelGGL(k_trace_rays, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, ctx->d_scene, (long long)n,
                            d_o, d_d, max_depth, accel, d_hits, d_rad, ctx->d_counters);
         e = hipGetLastError();
     }
@@ -1714,7 +1760,7 @@ extern "C" int rt_intersect_object(rt_ctx *ctx, int32_t object, int64_t n, const
     if (e == hipSuccess) { tmp.push_back(d_hits); e = hipMemcpyAsync(d_o, o, 3 * n * sizeof(float), hipMemcpyHostToDevice, ctx->stream); }
     if (e == hipSuccess) e = hipMemcpyAsync(d_d, d, 3 * n * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_intersect_object, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, ctx->S, object,
+        hipLaunchKernelGGL(k_intersect_object, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, ctx->d_scene, object,
                            (long long)n, d_o, d_d, accel, d_hits);
         e = hipGetLastError();
     }

@@ -110,8 +110,8 @@ inline std::string validate_scene(const rt_scene_desc *sc) {
         const rt_texture &t = sc->textures[i];
         if (t.kind < RT_TEX_CHECKER || t.kind > RT_TEX_IMAGE) return "bad texture kind";
         if (t.kind == RT_TEX_IMAGE && (!t.base_color || !t.normal || !t.occlusion || !t.roughness || t.width == 0 || t.height == 0 ||
-                                       (uint64_t)t.width * t.height > (1ull << 28)))
-            return "image texture needs four maps and a sane size";
+                                       t.width > 65535u || t.height > 65535u))
+            return "image texture needs four maps and a size of 1..65535 texels a side";
     }
     return "";
 }
@@ -340,8 +340,8 @@ inline int prepare_meshes(const rt_scene_desc *sc, std::vector<DevMesh> &meshes,
 
 // The shadow-query summaries per light (LightCull) and the mask of lights they are valid for.
 // Needs the world boxes prepare_meshes computed and the plane records' cannot_shadow bits.
-inline uint32_t make_light_cull(const rt_scene_desc *sc, const std::vector<DevMesh> &meshes, const std::vector<AxisPlaneRec> &axis,
-                                const std::vector<PlaneRec> &gen, std::vector<LightCull> &cull) {
+inline uint32_t make_light_cull(const rt_scene_desc *sc, const std::vector<DevMesh> &meshes, uint32_t planes_skip_lights,
+                                std::vector<LightCull> &cull) {
     LightCull none;
     for (int k = 0; k < kCullMeshes; k++) none.cone[k] = f4{0, 0, 0, 2.0f};
     cull.assign(std::max(sc->n_lights, 1), none);
@@ -353,9 +353,7 @@ inline uint32_t make_light_cull(const rt_scene_desc *sc, const std::vector<DevMe
     for (int i = 0; i < sc->n_objects; i++) quadrics = quadrics || sc->objects[i].kind == RT_OBJ_SPHERE || sc->objects[i].kind == RT_OBJ_CONE;
     if (quadrics || listed_meshes > kCullMeshes) return 0;
     for (int l = 0; l < sc->n_lights && l < 32; l++) {
-        bool ok = true;
-        for (const AxisPlaneRec &r : axis) if (r.axis != 0 && !((r.cannot_shadow >> l) & 1u)) ok = false;
-        for (const PlaneRec &r : gen) if (r.object >= 0 && !((r.cannot_shadow >> l) & 1u)) ok = false;
+        bool ok = ((planes_skip_lights >> l) & 1u) != 0;  // no plane can shadow this light
         int slot = 0;
         for (size_t i = 0; i < meshes.size() && ok; i++) {
             const DevMesh &m = meshes[i];
@@ -403,11 +401,18 @@ inline void make_srgb_lut(std::vector<float> &lut) {
     for (int b = 0; b < 256; b++) lut[b] = powf((float)b / 255.f, 2.2f);
 }
 
-// the plane records find_closest walks: planes that occur in the object list, split into
-// axis-aligned and general ones, each array padded with inert records to its group size
-inline void make_plane_recs(const rt_scene_desc *sc, const std::vector<int32_t> &plane_obj, std::vector<AxisPlaneRec> &axis,
-                            std::vector<PlaneRec> &gen) {
-    axis.clear(); gen.clear();
+// The plane records find_closest walks: the planes that occur in the object list, those with a normal +-e_a as
+// pairs per axis (pairs 0-2: the first plane of either orientation of x, y, z; pair 3 empty; overflow pairs from
+// kFixedAxisPairs on, padded to whole loads with empty pairs), the others as general records (padded to the group
+// size).  Returns the lights that no listed plane can shadow.
+inline uint32_t make_plane_recs(const rt_scene_desc *sc, const std::vector<int32_t> &plane_obj, std::vector<AxisPair> &axis,
+                                std::vector<PlaneRec> &gen) {
+    const AxisPair empty = {NAN, -1, 0, NAN, -1, 0, 0, 0};
+    axis.assign(kFixedAxisPairs, empty);
+    for (int a = 0; a < 3; a++) axis[a].axis = a;
+    axis[3].axis = -1;  // (never used)
+    gen.clear();
+    uint32_t skip = sc->n_lights >= 32 ? 0xffffffffu : (1u << std::max(sc->n_lights, 0)) - 1u;
     for (int i = 0; i < sc->n_planes; i++) {
         if (plane_obj[i] < 0) continue;
         const float *n = sc->planes[i].normal, *p = sc->planes[i].point;
@@ -420,13 +425,19 @@ inline void make_plane_recs(const rt_scene_desc *sc, const std::vector<int32_t> 
             for (int a = 0; a < 3; a++) { side += (double)n[a] * ((double)L[a] - p[a]); scale += std::fabs((double)L[a]) + std::fabs((double)p[a]); }
             if (side / nlen > 1e-3 * scale) cannot_shadow |= 1u << l;
         }
-        int ax = 0;
+        skip &= cannot_shadow;
+        int ax = -1;
+        bool positive = false;
         for (int a = 0; a < 3; a++)
-            if (std::fabs(n[a]) == 1.0f && n[(a + 1) % 3] == 0.0f && n[(a + 2) % 3] == 0.0f) ax = n[a] > 0 ? a + 1 : -(a + 1);
-        if (ax != 0) {
-            AxisPlaneRec r;
-            r.axis = ax; r.coord = p[std::abs(ax) - 1]; r.object = plane_obj[i]; r.cannot_shadow = cannot_shadow;
-            axis.push_back(r);
+            if (std::fabs(n[a]) == 1.0f && n[(a + 1) % 3] == 0.0f && n[(a + 2) % 3] == 0.0f) { ax = a; positive = n[a] > 0; }
+        if (ax >= 0) {
+            size_t at = axis.size();
+            for (size_t k = 0; k < axis.size(); k++)
+                if (axis[k].axis == ax && (positive ? axis[k].object_pos : axis[k].object_neg) < 0) { at = k; break; }
+            if (at == axis.size()) { axis.push_back(empty); axis.back().axis = ax; }
+            AxisPair &r = axis[at];
+            if (positive) { r.coord_pos = p[ax]; r.object_pos = plane_obj[i]; r.cs_pos = cannot_shadow; }
+            else { r.coord_neg = p[ax]; r.object_neg = plane_obj[i]; r.cs_neg = cannot_shadow; }
         } else {
             PlaneRec r;
             for (int a = 0; a < 3; a++) { r.n[a] = n[a]; r.p[a] = p[a]; }
@@ -434,8 +445,85 @@ inline void make_plane_recs(const rt_scene_desc *sc, const std::vector<int32_t> 
             gen.push_back(r);
         }
     }
-    while (axis.size() % kAxisPlaneGroup) axis.push_back(AxisPlaneRec{0, 0.0f, -1, 0});
+    while (axis.size() % kAxisPairGroup) axis.push_back(empty);
     while (gen.size() % kPlaneGroup) gen.push_back(PlaneRec{{0, 0, 0}, {0, 0, 0}, -1, 0});
+    return skip;
+}
+// upper bounds of the two arrays' sizes for a scene with n planes (rt_scene_update re-partitions them in place)
+inline size_t axis_pair_capacity(int n_planes) { return ((size_t)std::max(n_planes, 0) + 3 + kFixedAxisPairs + kAxisPairGroup) / kAxisPairGroup * kAxisPairGroup; }
+inline size_t gen_plane_capacity(int n_planes) { return ((size_t)std::max(n_planes, 0) + kPlaneGroup) / kPlaneGroup * kPlaneGroup; }
+
+// The materials as shading reads them (MatRec) and the per-object records (ObjRec).  tex_addr[i]: where texture
+// i's texel records live for the code that will read these tables (device address, or host address for a host build).
+inline void make_mat_recs(const rt_scene_desc *sc, const std::vector<const void *> &tex_addr, std::vector<MatRec> &out) {
+    out.assign(sc->n_materials, MatRec{});
+    for (int i = 0; i < sc->n_materials; i++) {
+        const rt_material &m = sc->materials[i];
+        MatRec &r = out[i];
+        for (int a = 0; a < 3; a++) {
+            r.ambient[a] = sc->ambient[a] * m.ambient[a];  // ambient_light * material.ambient, main.cpp:646
+            r.diffuse[a] = m.diffuse[a]; r.specular[a] = m.specular[a];
+        }
+        r.shininess = m.shininess; r.reflectiveness = m.reflectiveness; r.refractiveness = m.refractiveness;
+        r.refractive_ratio = m.refractive_ratio;
+        r.tex_wh = 0; r.tex_lo = 0; r.tex_hi = 0;
+        if (m.texture >= 0) {
+            const rt_texture &t = sc->textures[m.texture];
+            uint64_t addr = t.kind == RT_TEX_IMAGE ? (uint64_t)(uintptr_t)tex_addr[m.texture] : 0;
+            r.tex_wh = t.kind == RT_TEX_IMAGE ? (t.width | (t.height << 16)) : 0u;
+            r.tex_lo = (uint32_t)(addr & 0xfffffff0ull) | (uint32_t)(t.kind + 1);
+            r.tex_hi = (uint32_t)(addr >> 32);
+        }
+    }
+}
+inline void make_obj_recs(const rt_scene_desc *sc, const std::vector<MatRec> &mats, std::vector<ObjRec> &out) {
+    out.assign(std::max(sc->n_objects, 1), ObjRec{});
+    for (int i = 0; i < sc->n_objects; i++) {
+        const rt_object ob = sc->objects[i];
+        ObjRec &r = out[i];
+        r.kind = ob.kind; r.index = ob.index; r.material = -1; r.pad0 = 0;
+        if (ob.kind == RT_OBJ_PLANE) {
+            const rt_plane &pl = sc->planes[ob.index];
+            v3 n = ld3(pl.normal), nn = normalize(n);  // the reference's own float expression (glm::normalize)
+            r.n[0] = n.x; r.n[1] = n.y; r.n[2] = n.z; r.nn[0] = nn.x; r.nn[1] = nn.y; r.nn[2] = nn.z;
+            for (int a = 0; a < 3; a++) { r.b1[a] = pl.b1[a]; r.b2[a] = pl.b2[a]; }
+            r.material = pl.material;
+        } else if (ob.kind == RT_OBJ_SPHERE) {
+            r.material = sc->spheres[ob.index].material;
+        } else if (ob.kind == RT_OBJ_CONE) {
+            r.material = sc->cones[ob.index].material;
+        } else {  // a mesh: its material when all its triangles share one
+            const rt_mesh &m = sc->meshes[ob.index];
+            for (int t = 0; t < m.tri_count; t++) {
+                int tm = sc->tri_material[m.tri_offset + t];
+                if (t == 0) r.material = tm;
+                else if (tm != r.material) { r.material = -1; break; }
+            }
+        }
+        if (r.material >= 0) r.mat = mats[r.material];
+    }
+}
+
+// The per-light records: position, colour and the cones of make_light_cull.
+inline void make_light_recs(const rt_scene_desc *sc, const std::vector<LightCull> &cull, std::vector<LightRec> &out) {
+    out.assign(std::max(sc->n_lights, 1), LightRec{});
+    for (int l = 0; l < sc->n_lights; l++) {
+        LightRec &r = out[l];
+        for (int a = 0; a < 3; a++) { r.pos[a] = sc->light_pos[3 * l + a]; r.color[a] = sc->light_color[3 * l + a]; }
+        r.cull = cull[l];
+    }
+}
+// The tables that are part of the scene record itself: the fixed axis pairs and the first entries of the others.
+inline void fill_embedded(DevScene &S, const std::vector<AxisPair> &axis, const std::vector<PlaneRec> &gen, const std::vector<DevMesh> &meshes,
+                          const std::vector<ObjRec> &objs, const std::vector<LightRec> &lights) {
+    for (int i = 0; i < kFixedAxisPairs; i++) S.axis_pairs[i] = axis[i];
+    for (int i = 0; i < kEmbGenPlanes; i++) S.gen_first[i] = i < (int)gen.size() ? gen[i] : PlaneRec{{0, 0, 0}, {0, 0, 0}, -1, 0};
+    for (int i = 0; i < kEmbMeshes; i++) {
+        if (i < (int)meshes.size()) S.mesh_heads[i] = meshes[i];  // (the MeshHead part)
+        else { S.mesh_heads[i] = MeshHead{}; S.mesh_heads[i].object = -1; }
+    }
+    for (int i = 0; i < kEmbObjects; i++) S.obj_first[i] = i < (int)objs.size() ? objs[i] : ObjRec{};
+    for (int i = 0; i < kEmbLights; i++) S.light_first[i] = i < (int)lights.size() ? lights[i] : LightRec{};
 }
 
 }  // namespace rtc

@@ -22,7 +22,7 @@ struct VecStack {  // the host build's "wave" is one lane
     int32_t node[kStackDepth];
     uint64_t mask[kStackDepth];
     int max_sp = 0;
-    float cold[kColdSlots];
+    float cold[kColdSlots + kTapSlots];
     void cold_put(int slot, float v) { cold[slot] = v; }
     float cold_get(int slot) const { return cold[slot]; }
     void put(int slot, int32_t n, uint64_t m) { if (slot < kStackDepth) { node[slot] = n; mask[slot] = m; if (slot + 1 > max_sp) max_sp = slot + 1; } }
@@ -43,9 +43,12 @@ struct Twin {
     std::vector<int32_t> tri_orig, tri_material, tri_frag, tri_sub;
     std::vector<int32_t> plane_obj, sphere_obj, cone_obj, mesh_obj;
     std::vector<LightCull> light_cull;
+    std::vector<LightRec> light_recs;
     std::vector<SphereCull> sphere_cull;
-    std::vector<AxisPlaneRec> axis_planes;
+    std::vector<AxisPair> axis_pairs;
     std::vector<PlaneRec> gen_planes;
+    std::vector<MatRec> mat_recs;
+    std::vector<ObjRec> obj_recs;
     std::vector<float> ref_pos, leaf_box;  // pieces the triangles are cut into; boxes of the sorted pieces
     std::vector<int32_t> ref_tri;
     std::vector<float> tri_pos, tri_nrm, tri_uv, light_pos, light_color;
@@ -184,21 +187,26 @@ void *twin_create(const rt_scene_desc *sc, char *errbuf, int errcap) {
     S.n_planes = sc->n_planes; S.n_spheres = sc->n_spheres; S.n_cones = sc->n_cones; S.n_meshes = sc->n_meshes;
     kind_to_object(sc, t->plane_obj, t->sphere_obj, t->cone_obj, t->mesh_obj);
     for (int i = 0; i < sc->n_meshes; i++) t->meshes[i].object = t->mesh_obj[i];
-    make_plane_recs(sc, t->plane_obj, t->axis_planes, t->gen_planes);
-    S.n_axis_planes = (int32_t)t->axis_planes.size(); S.n_gen_planes = (int32_t)t->gen_planes.size();
-    S.axis_planes = t->axis_planes.data(); S.gen_planes = t->gen_planes.data();
+    S.planes_skip_lights = make_plane_recs(sc, t->plane_obj, t->axis_pairs, t->gen_planes);
+    S.n_axis_overflow = (int32_t)t->axis_pairs.size() - kFixedAxisPairs; S.n_gen_planes = (int32_t)t->gen_planes.size();
+    S.axis_overflow = t->axis_pairs.data() + kFixedAxisPairs; S.gen_planes = t->gen_planes.data();
+    std::vector<const void *> tex_addr(sc->n_textures, nullptr);
+    for (int i = 0; i < sc->n_textures; i++) tex_addr[i] = t->textures[i].texels;
+    make_mat_recs(sc, tex_addr, t->mat_recs);
+    make_obj_recs(sc, t->mat_recs, t->obj_recs);
+    S.mat_recs = t->mat_recs.data(); S.obj_recs = t->obj_recs.data();
     sphere_culls(sc, t->sphere_obj, t->sphere_cull);
     S.plane_obj = t->plane_obj.data(); S.sphere_cull = t->sphere_cull.data(); S.cone_obj = t->cone_obj.data();
     S.objects = t->objects.data(); S.spheres = t->spheres.data(); S.planes = t->planes.data(); S.cones = t->cones.data();
     S.meshes = t->meshes.data(); S.tri_test = t->tri_test.data(); S.tri_key = t->tri_key.data(); S.tri_orig = t->tri_orig.data();
     S.tri_nrm = t->tri_nrm.data(); S.tri_uv = t->tri_uv.data(); S.tri_material = t->tri_material.data();
     S.tri_frag = t->tri_frag.data(); S.tri_sub = t->tri_sub.data(); S.gate_tri = t->gate.data(); S.nodes = t->nodes.data();
-    S.cullable_lights = make_light_cull(sc, t->meshes, t->axis_planes, t->gen_planes, t->light_cull);
-    S.light_cull = t->light_cull.data();
+    S.cullable_lights = make_light_cull(sc, t->meshes, S.planes_skip_lights, t->light_cull);
+    make_light_recs(sc, t->light_cull, t->light_recs);
+    S.light_recs = t->light_recs.data();
     S.srgb_lut = t->srgb_lut.data(); S.gate_entry_first = (scene_features(sc) & F_SECONDARY) ? 1 : 0;
     S.materials = t->materials.data(); S.textures = t->textures.data();
-    S.light_pos = t->light_pos.data(); S.light_color = t->light_color.data();
-    for (int a = 0; a < 3; a++) S.ambient[a] = sc->ambient[a];
+    fill_embedded(S, t->axis_pairs, t->gen_planes, t->meshes, t->obj_recs, t->light_recs);
     return t;
 }
 
@@ -226,6 +234,7 @@ int twin_build_accel(void *h) {
         if (!(builder && std::strcmp(builder, "radix") == 0)) root = sah_children(n, leaf_box, c0, c1);
         t->build[mi].root = root;
         t->meshes[mi].root = root;
+        if (mi < (size_t)kEmbMeshes) t->S.mesh_heads[mi] = t->meshes[mi];  // (the copy in the scene record)
         for (int pass = 1; pass <= 4096; pass++) {
             int left = 0;
             for (int i = 0; i < n - 1; i++)
@@ -287,7 +296,7 @@ void twin_render(void *h, const rt_render_params *p, int x0, int y0, int x1, int
             VecStack stk;
             Work wk;
             work_zero(wk);
-            v3 c = render_pixel<F_ALL, true>(t->S, cam, p->mode, p->grid_m, p->max_depth, p->accel, i, j, grid_off, stk, wk);
+            v3 c = render_pixel<F_ALL, true, true>(t->S, cam, p->mode, p->grid_m, p->max_depth, p->accel, i, j, true, grid_off, stk, wk);
             size_t q = 3 * ((size_t)j * p->width + i);
             if (rgb) { rgb[q] = c.x; rgb[q + 1] = c.y; rgb[q + 2] = c.z; }
             if (rgb8) { v3 tm = tone_map(c); rgb8[q] = quantise(tm.x); rgb8[q + 1] = quantise(tm.y); rgb8[q + 2] = quantise(tm.z); }

@@ -120,6 +120,18 @@ def test_head_frame_sha256(anchors, oracle_scene, tmp_path):
     assert rays > 3 * 1024 * 768  # primary + shadow + refraction at least
 
 
+def test_head_frame_fixture_is_the_reference_frame(anchors, tmp_path):
+    """tests/golden/head_frame.npz (the frame the GPU test compares with) written through the oracle's P3 writer
+    hashes to the sha256 recorded from the reference binary's output file."""
+    import numpy as np
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "head_frame.npz"))
+    assert g["rgb8"].shape == (768, 1024, 3) and g["rgb_lattice"].shape == (192, 256, 3)
+    path = str(tmp_path / "head.ppm")
+    O.write_ppm(path, g["rgb8"])
+    assert hashlib.sha256(open(path, "rb").read()).hexdigest() == anchors["head_frame_sha256"]
+    assert bytes(g["sha256"]).decode() == anchors["head_frame_sha256"]
+
+
 def test_refract_anchors(anchors):
     import ctypes as C
     L = O.lib()
