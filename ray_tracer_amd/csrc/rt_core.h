@@ -13,6 +13,7 @@
 #pragma once
 
 #include <math.h>
+#include <stddef.h>
 #include <stdint.h>
 #include <string.h>
 
@@ -164,6 +165,14 @@ RT_HD u32x16 load_u32x16(const void *p) {  // p: 64-byte aligned on the device
     u32x16 v; memcpy(&v, p, sizeof v); return v;
 #endif
 }
+// the same 64 bytes through an address of the lane's own (vector loads)
+RT_HD u32x16 load_u32x16_lane(const void *p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return *reinterpret_cast<const u32x16 *>(p);
+#else
+    u32x16 v; memcpy(&v, p, sizeof v); return v;
+#endif
+}
 RT_HD float u2f(uint32_t u) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return __uint_as_float(u);
@@ -191,6 +200,17 @@ RT_HD v3 m3_mul(v3 c0, v3 c1, v3 c2, v3 v) {
 // c ? a : b by components (the conditional operator on the structs themselves selects between their ADDRESSES, and
 // the compiler then keeps both in private memory and loads through the selected address)
 RT_HD v3 select3(bool c, v3 a, v3 b) { return V3(c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z); }
+// v as a value the optimiser must treat as computed HERE from `with`: what is derived from it is derived again, not
+// kept in registers from an earlier, identical derivation (used where recomputing a few values after a traversal is
+// cheaper than holding them through it)
+RT_HD v3 again(v3 v, float with) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("" : "+v"(v.x), "+v"(v.y), "+v"(v.z) : "v"(with));
+#else
+    (void)with;
+#endif
+    return v;
+}
 RT_HD float clamp01(float x) { float m = (x < 0.0f) ? 0.0f : x; return (1.0f < m) ? 1.0f : m; }
 
 // ---------------------------------------------------------------- device-side scene
@@ -393,6 +413,11 @@ RT_HD SceneRef fresh(SceneRef S, float) { return S; }
 RT_HD SceneRef scene_ref(const DevScene *p) { return *p; }
 #endif
 
+static_assert(offsetof(DevScene, n_axis_overflow) == 4 && offsetof(DevScene, n_gen_planes) == 8 && offsetof(DevScene, n_meshes) == 12 &&
+                  offsetof(DevScene, n_spheres) == 16 && offsetof(DevScene, n_cones) == 20 && offsetof(DevScene, axis_overflow) == 32 &&
+                  offsetof(DevScene, axis_pairs) == 64 && offsetof(DevScene, mesh_heads) % 64 == 0 && offsetof(DevScene, obj_first) % 64 == 0 &&
+                  offsetof(DevScene, light_first) % 64 == 0,
+              "find_closest reads the first 64 bytes of the scene record as one load");
 // Where record i of a table lives: in the scene record itself (an address known without a load), or behind the
 // table's pointer.  The pointer is read in the branch that needs it, through a reference of its own (fresh), so that
 // the common case never waits for it.
@@ -898,13 +923,13 @@ RT_HD bool mesh_geom(SceneRef S, const MeshHead &h, const DevMesh &m, v3 ro, v3 
     if (wave_ballot(want) == 0) return false;  // the whole wave misses the mesh's world box
     v3 d = xform_dir(m.to_local, rd);
     v3 o = xform_point(m.to_local, ro);
-    v3 bo = o, bd = d;
-    if (!h.same_xform) {
-        bd = xform_dir(m.box_to_local, rd);
-        bo = xform_point(m.box_to_local, ro);
-    }
     {   // evaluated for every mesh (no branch, so that to_local and the boxes arrive in one batch of loads);
         // the outcome only counts for boxed meshes
+        v3 bo = o, bd = d;  // the ray in the Box's own space
+        if (!h.same_xform) {
+            bd = xform_dir(m.box_to_local, rd);
+            bo = xform_point(m.box_to_local, ro);
+        }
         bool boxed = h.boxed != 0;
         v3 binv = V3(safe_rcp(bd.x), safe_rcp(bd.y), safe_rcp(bd.z));
         if (COUNT && want && boxed) wk.box++;
@@ -929,6 +954,11 @@ RT_HD bool mesh_geom(SceneRef S, const MeshHead &h, const DevMesh &m, v3 ro, v3 
     if (best.k < 0) return false;
     if (h.boxed) {
         if (COUNT) wk.gate++;
+        // the ray in the Box's space once more (the same arithmetic as above: formed again here rather than held in six
+        // registers through the traversal)
+        const float *to_box = h.same_xform ? m.to_local : m.box_to_local;
+        const v3 rd2 = again(rd, best.t), ro2 = again(ro, best.t);
+        const v3 bd = xform_dir(to_box, rd2), bo = xform_point(to_box, ro2);
         const f4 *gt = S.gate_tri + 3 * (size_t)h.gate_tri_offset;
         bool any = false;
         // The gate is the OR of the 12 one-sided triangle tests, so their order is free.  ENTRY_FIRST (the kernels for scenes
@@ -1066,7 +1096,7 @@ RT_HD void plane_axis_pair(float coord_pos, int32_t object_pos, float coord_neg,
     const bool down = d_a < 0;
     const float coord = down ? coord_pos : coord_neg;
     const int32_t object = down ? object_pos : object_neg;
-    if (COUNT && coord == coord) wk.plane++;
+    if (COUNT) wk.plane += (coord_pos == coord_pos ? 1u : 0u) + (coord_neg == coord_neg ? 1u : 0u);  // one estimate decides both tests
     const float q = coord - o_a;
     plane_candidate(c, q * r_a, q, d_a, object);
 }
@@ -1096,21 +1126,28 @@ RT_HD void planes_exact(SceneRef S, v3 ro, v3 rd, Closest &best, Work &wk) {
         best.distance = ok ? t : best.distance; best.object = ok ? idx : best.object; best.t = ok ? t : best.t;
     }
 }
-// rinv: 1-ulp reciprocals of the direction's components
+// rinv: 1-ulp reciprocals of the direction's components; g0, g1: the fixed axis pairs (S.axis_pairs as two loads);
+// n_axis_overflow, n_gen_planes, axis_overflow: the scene record's fields of these names
 template <bool COUNT>
-RT_HD void planes_pass(SceneRef S, v3 ro, v3 rd, v3 rinv, uint32_t light_bit, Closest &best, Work &wk) {
+RT_HD void planes_pass(SceneRef S, const u32x16 &g0, const u32x16 &g1, int32_t n_axis_overflow, int32_t n_gen_planes, const AxisPair *axis_overflow,
+                       v3 ro, v3 rd, v3 rinv, uint32_t light_bit, Closest &best, Work &wk) {
     PlaneCand c;
     c.est = INFINITY; c.second = INFINITY; c.P = 0; c.D = 1; c.object = -1;
     {
-        u32x16 g0 = load_u32x16((const void *)(uintptr_t)&S.axis_pairs[0]), g1 = load_u32x16((const void *)(uintptr_t)&S.axis_pairs[2]);
-        pin_scalar(g0); pin_scalar(g1);
-        plane_axis_pair<COUNT>(pair_coord(g0[0], g0[2], light_bit), (int32_t)g0[1], pair_coord(g0[3], g0[5], light_bit), (int32_t)g0[4], ro.x, rd.x, rinv.x, c, wk);
-        plane_axis_pair<COUNT>(pair_coord(g0[8], g0[10], light_bit), (int32_t)g0[9], pair_coord(g0[11], g0[13], light_bit), (int32_t)g0[12], ro.y, rd.y, rinv.y, c, wk);
-        plane_axis_pair<COUNT>(pair_coord(g1[0], g1[2], light_bit), (int32_t)g1[1], pair_coord(g1[3], g1[5], light_bit), (int32_t)g1[4], ro.z, rd.z, rinv.z, c, wk);
+        // (a shadow ray's wave skips a pair neither of whose planes can shadow its light: wave-uniform; for other rays
+        // light_bit is a constant 0 and the checks fold away)
+#define RT_PAIR_LIVE(g, at) (light_bit == 0 || ((int32_t)g[at + 1] >= 0 && (g[at + 2] & light_bit) == 0) || ((int32_t)g[at + 4] >= 0 && (g[at + 5] & light_bit) == 0))
+        if (RT_PAIR_LIVE(g0, 0))
+            plane_axis_pair<COUNT>(pair_coord(g0[0], g0[2], light_bit), (int32_t)g0[1], pair_coord(g0[3], g0[5], light_bit), (int32_t)g0[4], ro.x, rd.x, rinv.x, c, wk);
+        if (RT_PAIR_LIVE(g0, 8))
+            plane_axis_pair<COUNT>(pair_coord(g0[8], g0[10], light_bit), (int32_t)g0[9], pair_coord(g0[11], g0[13], light_bit), (int32_t)g0[12], ro.y, rd.y, rinv.y, c, wk);
+        if (RT_PAIR_LIVE(g1, 0))
+            plane_axis_pair<COUNT>(pair_coord(g1[0], g1[2], light_bit), (int32_t)g1[1], pair_coord(g1[3], g1[5], light_bit), (int32_t)g1[4], ro.z, rd.z, rinv.z, c, wk);
+#undef RT_PAIR_LIVE
     }
     // overflow pairs (an axis with several planes of one orientation): the axis is a wave-uniform value
-    for (int32_t i = 0; i < S.n_axis_overflow; i += 2) {
-        u32x16 g = load_u32x16(S.axis_overflow + i);
+    for (int32_t i = 0; i < n_axis_overflow; i += 2) {
+        u32x16 g = load_u32x16(axis_overflow + i);
         pin_scalar(g);
         for (int at = 0; at < 16; at += 8) {
             const int32_t a = (int32_t)g[at + 6];
@@ -1120,21 +1157,25 @@ RT_HD void planes_pass(SceneRef S, v3 ro, v3 rd, v3 rinv, uint32_t light_bit, Cl
                                    (int32_t)g[at + 4], o_a, d_a, r_a, c, wk);
         }
     }
-    for (int32_t i = 0; i < S.n_gen_planes; i += kPlaneGroup) {
+    for (int32_t i = 0; i < n_gen_planes; i += kPlaneGroup) {
         u32x16 g = load_u32x16(gen_plane_at(S, i, rd.y));
         pin_scalar(g);
         plane_general<COUNT>(g, 0, light_bit, ro, rd, c, wk);
         plane_general<COUNT>(g, 8, light_bit, ro, rd, c, wk);
     }
+    if (light_bit != 0 && wave_ballot(c.est < INFINITY) == 0) {  // (shadow rays mostly find no plane ahead at all)
+        best.distance = INFINITY; best.object = -1; best.t = 0;
+        return;
+    }
     const float t = c.P / c.D;  // the reference's quotient (main.cpp:233) for the lane's winner
-    // With a non-finite component the reference's dot products with +-e_a are NaN and the plane is missed; the general
-    // planes' own dot products say so themselves.  (Judged for the lane's winner, whichever kind it is: a ray with a
-    // non-finite component misses every plane.)
-    float adx = fabsf(rd.x), ady = fabsf(rd.y), adz = fabsf(rd.z), aox = fabsf(ro.x), aoy = fabsf(ro.y), aoz = fabsf(ro.z);
-    const uint64_t finite = wave_ballot(adx < INFINITY) & wave_ballot(ady < INFINITY) & wave_ballot(adz < INFINITY) &
-                            wave_ballot(aox < INFINITY) & wave_ballot(aoy < INFINITY) & wave_ballot(aoz < INFINITY);
-    const bool has = wave_mask_bit(finite & wave_ballot(c.est < INFINITY));
-    const bool unsure = has & (!(c.second > c.est * 1.00001f) | !(t > kMinDist) | !(t < INFINITY));
+    // With a non-finite component the reference's dot products with +-e_a are NaN and the plane is missed (the general
+    // planes' own dot products say so themselves): nf is +-0 for a finite ray and NaN otherwise, and a ray with a
+    // non-finite component misses every plane.
+    const float nf = (rd.x * 0.0f + rd.y * 0.0f + rd.z * 0.0f) + (ro.x * 0.0f + ro.y * 0.0f + ro.z * 0.0f);
+    const float e = c.est + nf;
+    const bool has = e < INFINITY;
+    // (an estimate so large that e * 1.00001f is infinite counts as unsure too: the exact quotient may not be finite)
+    const bool unsure = has & (!(c.second > e * 1.00001f) | !(t > kMinDist));
     if (wave_ballot(unsure) != 0) {
         planes_exact<COUNT>(S, ro, rd, best, wk);
         return;
@@ -1154,10 +1195,20 @@ RT_HD void find_closest(SceneRef scene, v3 ro, v3 rd, int accel, int light, floa
     best.t = 0;
     best.k = 0;
     const v3 rinv = V3(shade_rcp(rd.x), shade_rcp(rd.y), shade_rcp(rd.z));  // estimates and box tests only, never a hit decision
-    if ((S.planes_skip_lights & light_bit) == 0) planes_pass<COUNT>(S, ro, rd, rinv, light_bit, best, wk);
-    const bool meshes = (F & F_MESH) && S.n_meshes > 0;
+    // everything the query reads of the scene record in one batch of loads: its first 64 bytes (counts and table
+    // pointers), the fixed axis pairs and the first mesh's head
+    u32x16 hdr = load_u32x16((const void *)(uintptr_t)&S.planes_skip_lights);
+    u32x16 g0 = load_u32x16((const void *)(uintptr_t)&S.axis_pairs[0]), g1 = load_u32x16((const void *)(uintptr_t)&S.axis_pairs[2]);
+    u32x16 head0 = (F & F_MESH) ? load_u32x16((const void *)(uintptr_t)&S.mesh_heads[0]) : g0;
+    pin_scalar(hdr); pin_scalar(g0); pin_scalar(g1);
+    const int32_t n_axis_overflow = (int32_t)hdr[1], n_gen_planes = (int32_t)hdr[2], n_meshes = (int32_t)hdr[3];
+    const int32_t n_spheres = (int32_t)hdr[4], n_cones = (int32_t)hdr[5];
+    if ((hdr[0] & light_bit) == 0)
+        planes_pass<COUNT>(S, g0, g1, n_axis_overflow, n_gen_planes, reinterpret_cast<const AxisPair *>((uintptr_t)(((uint64_t)hdr[9] << 32) | hdr[8])),
+                           ro, rd, rinv, light_bit, best, wk);
+    const bool meshes = (F & F_MESH) && n_meshes > 0;
     if (F & F_QUADRIC)
-    for (int32_t i = 0; i < S.n_spheres; i++) {
+    for (int32_t i = 0; i < n_spheres; i++) {
         QuadricHit q;
         const SphereCull &k = S.sphere_cull[i];
         int32_t idx = k.object;
@@ -1169,7 +1220,7 @@ RT_HD void find_closest(SceneRef scene, v3 ro, v3 rd, int accel, int light, floa
         }
     }
     if (F & F_QUADRIC)
-    for (int32_t i = 0; i < S.n_cones; i++) {
+    for (int32_t i = 0; i < n_cones; i++) {
         QuadricHit q;
         if (COUNT) wk.quadric++;
         int32_t idx = S.cone_obj[i];
@@ -1179,14 +1230,16 @@ RT_HD void find_closest(SceneRef scene, v3 ro, v3 rd, int accel, int light, floa
         }
     }
     if (meshes) {
-    v3 winv = V3(safe_rcp_of(rd.x, rinv.x), safe_rcp_of(rd.y, rinv.y), safe_rcp_of(rd.z, rinv.z));
-    v3 woi = ro * winv;
     bool nan_o = has_nan(ro), nan_d = has_nan(rd);
     bool valid = !(nan_o | nan_d);  // every triangle test fails on NaN inputs
-    const int32_t n_meshes = S.n_meshes;
     for (int32_t i = 0; i < n_meshes; i++) {
+        // (the reciprocals per mesh, not held through the traversal of the mesh before)
+        const v3 rdi = again(rd, best.distance);
+        const v3 winv = V3(safe_rcp(rdi.x), safe_rcp(rdi.y), safe_rcp(rdi.z));
+        const v3 woi = ro * winv;
         union { u32x16 raw; MeshHead h; } head;
-        head.raw = load_u32x16(mesh_head_at(S, i, rd.y));
+        if (i == 0) { pin_scalar(head0); head.raw = head0; }
+        else head.raw = load_u32x16(mesh_head_at(S, i, rd.y));
         int32_t idx = head.h.object;
         if (idx < 0) continue;  // wave-uniform
         MeshHit mh;
@@ -1474,25 +1527,13 @@ RT_HD void surface_shade(SceneRef scene, const Closest &c, bool hit, v3 ro, v3 r
             u32x16 g = load_u32x16(rec), mr = load_u32x16(rec + 64);
             pin_scalar(g); pin_scalar(mr);
             shade_object<F, COUNT>(S, g, mr, c, ro, rd, sc, wk);
-        } else {
-            // several objects: one after the other, each for the lanes that hit it.  The results go through the parking
-            // columns: a context built up in registers around the loop would be carried, and copied, in every round.
-            bool todo = hit;
-            while (wave_ballot(todo) != 0) {
-                if (todo) {
-                    const int32_t o2 = wave_uniform(c.object);  // (the first lane that is still to do)
-                    if (c.object == uniform_alias(o2)) {
-                        todo = false;
-                        const char *rec = obj_rec_at(S, o2, c.distance);
-                        u32x16 g = load_u32x16(rec), mr = load_u32x16(rec + 64);
-                        pin_scalar(g); pin_scalar(mr);
-                        ShadeCtx mine;
-                        shade_object<F, COUNT>(S, g, mr, c, ro, rd, mine, wk);
-                        park_shade<F>(stk, mine);
-                    }
-                }
-            }
-            unpark_shade<F>(stk, sc);
+        } else if (hit) {
+            // several objects: every lane reads the record of its own (vector loads) and the lanes go through the
+            // object kinds side by side.  (Taking the objects in turn with scalar records repeats a kind's arithmetic
+            // for every object of that kind, and a wave on a silhouette has three or four.)
+            const char *rec = reinterpret_cast<const char *>(S.obj_recs + c.object);
+            u32x16 g = load_u32x16_lane(rec), mr = load_u32x16_lane(rec + 64);
+            shade_object<F, COUNT>(S, g, mr, c, ro, rd, sc, wk);
         }
     }
     if (!hit) sc.point = V3(NAN, NAN, NAN);
@@ -1539,69 +1580,71 @@ RT_HD void shade_lights(SceneRef scene, bool hit, int accel, ShadeCtx &sc, Stack
     const int32_t n_lights = S0.n_lights;
     const uint32_t cullable_lights = S0.cullable_lights;
     for (int32_t l = 0; l < n_lights; l++) {
+        const bool cullable = l < 32 && ((cullable_lights >> l) & 1u);  // (wave-uniform)
+        const char *rec = light_rec_at(fresh(scene, sc.point.y), l, sc.point.z);
+        u32x16 lr = load_u32x16(rec);
+        pin_scalar(lr);
+        v3 light_color = V3(u2f(lr[4]), u2f(lr[5]), u2f(lr[6]));
+        v3 Lv = V3(u2f(lr[0]), u2f(lr[1]), u2f(lr[2])) - sc.point;
+        float d2 = dot(Lv, Lv);
         bool traced = hit;  // this lane's shadow ray has to be traced
-        {
-            SceneRef S = fresh(scene, sc.point.y);
-            if (l < 32 && ((cullable_lights >> l) & 1u)) {
-                const char *rec = light_rec_at(S, l, sc.point.z);
-                u32x16 lr = load_u32x16(rec), lc = load_u32x16(rec + 64);
-                pin_scalar(lr); pin_scalar(lc);
-                v3 Lv = V3(u2f(lr[0]), u2f(lr[1]), u2f(lr[2])) - sc.point;
-                v3 La = Lv * shade_rsq(dot(Lv, Lv));
-                // slots are filled in order and an unused one holds cos = 2 (never inside): stop at the first
-                bool in = !(dot(La, V3(u2f(lc[0]), u2f(lc[1]), u2f(lc[2]))) < u2f(lc[3]));
-                if (lc[7] != kUnusedCone) {
-                    in |= !(dot(La, V3(u2f(lc[4]), u2f(lc[5]), u2f(lc[6]))) < u2f(lc[7]));
-                    if (lc[11] != kUnusedCone) {
-                        in |= !(dot(La, V3(u2f(lc[8]), u2f(lc[9]), u2f(lc[10]))) < u2f(lc[11]));
-                        if (lc[15] != kUnusedCone) in |= !(dot(La, V3(u2f(lc[12]), u2f(lc[13]), u2f(lc[14]))) < u2f(lc[15]));
-                    }
+        if (cullable) {
+            u32x16 lc = load_u32x16(rec + 64);
+            pin_scalar(lc);
+            v3 La = Lv * shade_rsq(d2);
+            // slots are filled in order and an unused one holds cos = 2 (never inside): stop at the first
+            bool in = !(dot(La, V3(u2f(lc[0]), u2f(lc[1]), u2f(lc[2]))) < u2f(lc[3]));
+            if (lc[7] != kUnusedCone) {
+                in |= !(dot(La, V3(u2f(lc[4]), u2f(lc[5]), u2f(lc[6]))) < u2f(lc[7]));
+                if (lc[11] != kUnusedCone) {
+                    in |= !(dot(La, V3(u2f(lc[8]), u2f(lc[9]), u2f(lc[10]))) < u2f(lc[11]));
+                    if (lc[15] != kUnusedCone) in |= !(dot(La, V3(u2f(lc[12]), u2f(lc[13]), u2f(lc[14]))) < u2f(lc[15]));
                 }
-                traced = hit & in;
             }
+            traced = hit & in;
         }
         const uint64_t traced_mask = wave_ballot(traced);
-        bool lit = hit;
-        if (traced_mask != 0) {  // (wave-uniform)
-            const char *rec = light_rec_at(fresh(scene, sc.point.y), l, sc.point.z);
-            u32x16 lr = load_u32x16(rec);
-            pin_scalar(lr);
-            v3 Lv = V3(u2f(lr[0]), u2f(lr[1]), u2f(lr[2])) - sc.point;
-            float len = sqrtf(dot(Lv, Lv));
-            v3 L = Lv * (1.0f / len);       // glm::normalize(light - point)
-            if (!traced) L = V3(NAN, NAN, NAN);
-            park_shade<F>(stk, sc);
-            Closest cs;
-            // |L| = 1, so the local ray parameter equals the world distance up to rounding: clip there
-            find_closest<F, COUNT>(scene, sc.point + L * kEps, L, accel, l, len * 1.001f + 1e-3f, len, cs, stk, wk);
-            unpark_shade<F>(stk, sc);
-            // (the distance again from the parked point and the light's record: nothing but the parked values lives across the query)
-            u32x16 lr2 = load_u32x16(light_rec_at(fresh(scene, sc.point.y), l, sc.point.z));
-            pin_scalar(lr2);
-            v3 Lv2 = V3(u2f(lr2[0]), u2f(lr2[1]), u2f(lr2[2])) - sc.point;
-            float len2 = sqrtf(dot(Lv2, Lv2));
-            lit = hit & !(wave_mask_bit(traced_mask) & (cs.distance < len2));
-        }
         if (hit) {
             wk.rays_shadow++;
-            if (wave_mask_bit(traced_mask)) wk.shadow_q++;
+            if (traced) wk.shadow_q++;
         }
-        {
-            u32x16 lr = load_u32x16(light_rec_at(fresh(scene, sc.point.y), l, sc.point.z));
-            pin_scalar(lr);
-            v3 Lv = V3(u2f(lr[0]), u2f(lr[1]), u2f(lr[2])) - sc.point;
-            float d2 = dot(Lv, Lv);
-            float ri = shade_rsq(d2);
-            v3 L = Lv * ri;
-            float r = d2 * ri;
-            if (traced_mask != 0) {  // the exact forms for the lanes whose ray was traced
+        bool lit = hit;
+        v3 L;
+        float r;
+        if (traced_mask != 0) {  // (wave-uniform)
+            {
                 float len = sqrtf(d2);
-                v3 Le = Lv * (1.0f / len);
+                v3 Le = Lv * (1.0f / len);  // glm::normalize(light - point)
+                if (!traced) Le = V3(NAN, NAN, NAN);
+                park_shade<F>(stk, sc);
+                Closest cs;
+                // |L| = 1, so the local ray parameter equals the world distance up to rounding: clip there
+                find_closest<F, COUNT>(scene, sc.point + Le * kEps, Le, accel, l, len * 1.001f + 1e-3f, len, cs, stk, wk);
+                unpark_shade<F>(stk, sc);
+                // (everything that follows is formed again from the parked point and the light's record: nothing but
+                // the parked values lives across the query)
+                u32x16 lr2 = load_u32x16(light_rec_at(fresh(scene, sc.point.y), l, sc.point.z));
+                pin_scalar(lr2);
+                light_color = V3(u2f(lr2[4]), u2f(lr2[5]), u2f(lr2[6]));
+                v3 Lv2 = V3(u2f(lr2[0]), u2f(lr2[1]), u2f(lr2[2])) - sc.point;
+                float d2b = dot(Lv2, Lv2);
+                float len2 = sqrtf(d2b);
                 const bool mine = wave_mask_bit(traced_mask);
-                L = select3(mine, Le, L); r = mine ? len : r;
+                lit = hit & !(mine & (cs.distance < len2));
+                L = Lv2 * (1.0f / len2);
+                r = len2;
+                if (cullable) {  // the lanes whose ray was not traced: the 1-ulp forms, as in a wave that traces nothing
+                    float ri = shade_rsq(d2b);
+                    L = select3(mine, L, Lv2 * ri);
+                    r = mine ? r : d2b * ri;
+                }
             }
-            if (lit) shade_light<COUNT>(sc, V3(u2f(lr[4]), u2f(lr[5]), u2f(lr[6])), L, r, wk);
+        } else {
+            float ri = shade_rsq(d2);
+            L = Lv * ri;
+            r = d2 * ri;
         }
+        if (lit) shade_light<COUNT>(sc, light_color, L, r, wk);
     }
 }
 
@@ -1628,10 +1671,10 @@ struct Pending { v3 o, d; float w; int32_t depth; };
 // wave-uniform value and neither a ray stage nor a pending stack has to be carried.
 template <int F, bool COUNT, class Stack, class Source>
 RT_HD void trace_loop_direct(SceneRef S, int accel, Stack &stk, Work &wk, Source &src) {
-    v3 o, d;
-    bool live = src.next(o, d);  // (a source may hand a lane no ray while others get one: all lanes call next() alike, in step)
-    bool more = true;
-    while (wave_ballot(live) != 0) {
+    for (;;) {
+        v3 o, d;
+        const bool live = src.next(o, d);  // (all lanes call next() alike, in step; a source may hand a lane no ray while others get one)
+        if (wave_ballot(live) == 0) break;
         Closest c;
         find_closest<F, COUNT>(S, o, d, accel, -1, INFINITY, -INFINITY, c, stk, wk);
         if (live) wk.rays_primary++;
@@ -1644,10 +1687,7 @@ RT_HD void trace_loop_direct(SceneRef S, int accel, Stack &stk, Work &wk, Source
         v3 radiance = V3(0, 0, 0);
         if (hit) radiance = radiance + shade_end(sc) * 1.0f;
         if (live) src.done(radiance);
-        more = src.next(o, d);
-        live = live & more;
     }
-    (void)more;
 }
 
 template <int F, bool COUNT, class Stack, class Source>
