@@ -49,7 +49,7 @@ constexpr int render_waves(int features, bool count) {
 // (the kernels with two bodies have more to keep: at 6 waves the per-tile kernel is 13 % slower than at 5)
 // (measured on the shells frame: 130 registers at 3 waves 40.7 ms, 121 at 4 waves 41.8 ms: these instantiations want registers
 // more than they want waves)
-constexpr int split_waves(int features, bool count) { return (features & F_SECONDARY) ? 3 : render_waves(features, count); }
+constexpr int split_waves(int features, bool count) { return (features & F_SECONDARY) ? 4 : render_waves(features, count); }
 constexpr int kVariantQueue = 4;     // k_render_queue
 constexpr int kWavesPerBlock = kBlock / 64;
 constexpr int kStackWords = 3 * kStackDepth;
@@ -72,9 +72,11 @@ struct WaveStack {
         mask = ((uint64_t)hi << 32) | lo;
     }
 };
-#define RT_WAVE_STACK(name, features, tap_slots)                         \
+// extra: columns after the cold_slots(features) ones: kTapSlots for a pixel's tap state (PixelTaps), kSplitSlots for the
+// kernels that spread taps over waves (the pixel's corner, then the round's tap results: see split_tap_lds)
+#define RT_WAVE_STACK(name, features, extra)                             \
     __shared__ uint32_t name##_lds[kWavesPerBlock * kStackWords];        \
-    __shared__ float name##_cold[(cold_slots(features) + ((tap_slots) ? kTapSlots : 0)) * kBlock]; \
+    __shared__ float name##_cold[(cold_slots(features) + (extra)) * kBlock]; \
     WaveStack name;                                                      \
     name.base = name##_lds + (threadIdx.x >> 6) * kStackWords;           \
     name.cold = name##_cold + threadIdx.x
@@ -424,7 +426,7 @@ template <int F, bool COUNT>
 __global__ __launch_bounds__(kBlock, render_waves(F, COUNT)) void k_render(const DevScene *scene, RenderArgs a, float *rgb_tiles, uint8_t *rgb8_tiles,
                                                    unsigned long long *counters) {
     SceneRef S = scene_ref(scene);
-    RT_WAVE_STACK(stk, F, true);
+    RT_WAVE_STACK(stk, F, kTapSlots);
     __shared__ float s_grid_off[kMaxGrid];
     fill_grid_table(s_grid_off, a);
     Work wk;
@@ -441,10 +443,19 @@ __global__ __launch_bounds__(kBlock, render_waves(F, COUNT)) void k_render(const
 // taps are traced in one step.  This bounds the time of the most expensive block to a quarter (an eighth),
 // which is what limits frames whose cost is concentrated in few pixels and launches of few tiles.
 constexpr int kRoundTaps = 8;
-struct TapSlice {  // a trace_loop source: taps [k, k_end) of one pixel
+// LDS columns of the tap-splitting kernels after the shading columns: two for the pixel's corner, then the results of a
+// round's taps, kRoundTaps * 3 * 64 floats (one lane-pixel each; 6 columns of kBlock floats).  A block that renders a
+// whole tile one pixel per lane instead (the per-tile kernel's light tiles) keeps that pixel's tap state (kTapSlots
+// columns) in the same place.
+constexpr int kSplitSlots = 2 + kRoundTaps * 3 * 64 / kBlock;
+static_assert(kRoundTaps * 3 * 64 % kBlock == 0 && kSplitSlots >= kTapSlots, "tap results fill whole columns");
+template <int F>
+__device__ __forceinline__ float *split_tap_lds(WaveStack &stk) { return stk.cold - threadIdx.x + (cold_slots(F) + 2) * kBlock; }
+template <int BASE>
+struct TapSlice {  // a trace_loop source: taps [k, k_end) of one pixel; the pixel's corner in columns BASE, BASE + 1 of stk
     Camera cam;
     int mode, grid_m, k, k_end, base;
-    float dx, dy;           // the pixel's corner (pixel_dx, pixel_dy)
+    WaveStack *stk;
     bool inside;            // the lane has a pixel of the frame and taps of its own in this round
     int col, row;           // GRID: k = row * grid_m + col
     const float *grid_off;  // GRID: the block's table of grid_offset(a, grid_m, cam.s)
@@ -455,6 +466,7 @@ struct TapSlice {  // a trace_loop source: taps [k, k_end) of one pixel
     __device__ bool next(v3 &ro, v3 &rd) {
         if (k >= k_end) return false;
         ro = V3(0, 0, 0);
+        const float dx = stk->cold_get(BASE), dy = stk->cold_get(BASE + 1);
         if (mode == RT_MODE_GRID) {
             rd = primary_dir_grid(dx, dy, grid_off[col], grid_off[row]);
             wt = 1.0f;
@@ -482,7 +494,8 @@ struct TapSlice {  // a trace_loop source: taps [k, k_end) of one pixel
 // kRoundTaps and summed in tap order through LDS (tap_lds: kRoundTaps * 3 * 64 floats), as render_tile_part does.
 template <int F>
 __device__ __forceinline__ void render_item(SceneRef S, const RenderArgs &a, int local, int part, WaveStack &stk, const float *grid_off,
-                                            float *tap_lds, float *rgb_tiles, uint8_t *rgb8_tiles, Work &wk) {
+                                            float *rgb_tiles, uint8_t *rgb8_tiles, Work &wk) {
+    float *tap_lds = split_tap_lds<F>(stk);
     const bool whole = part < 0;  // (block-uniform)
     const int tile = shard_tile(local, a.rank, a.world_size);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -492,12 +505,13 @@ __device__ __forceinline__ void render_item(SceneRef S, const RenderArgs &a, int
     const bool inside = tile < a.tiles_total && i < a.width && j < a.height;
     const int taps = taps_of(a.mode, a.grid_m);
     const int round_taps = whole ? taps : kRoundTaps;
+    stk.cold_put(cold_slots(F), pixel_dx(a.cam, i)); stk.cold_put(cold_slots(F) + 1, pixel_dy(a.cam, j));
     v3 color = V3(0, 0, 0);
     for (int base = 0; base < taps; base += round_taps) {
         const int n = taps - base < round_taps ? taps - base : round_taps;
         const int chunk = whole ? n : (n + 3) / 4, slot = whole ? 0 : wave;
-        TapSlice src;
-        src.cam = a.cam; src.mode = a.mode; src.grid_m = a.grid_m; src.dx = pixel_dx(a.cam, i); src.dy = pixel_dy(a.cam, j); src.base = base; src.wt = 1.0f;
+        TapSlice<cold_slots(F)> src;
+        src.cam = a.cam; src.mode = a.mode; src.grid_m = a.grid_m; src.stk = &stk; src.base = base; src.wt = 1.0f;
         src.k = base + (slot * chunk < n ? slot * chunk : n);
         src.k_end = base + ((slot + 1) * chunk < n ? (slot + 1) * chunk : n);
         src.col = src.k % a.grid_m; src.row = src.k / a.grid_m; src.grid_off = grid_off;
@@ -535,7 +549,8 @@ __device__ __forceinline__ void render_item(SceneRef S, const RenderArgs &a, int
 // Part `part` (of 4 * PH) of local tile `local` by one block; tap_lds: kRoundTaps * 3 * (64 / PH) floats of LDS.
 template <int F, bool COUNT, int PH>
 __device__ __forceinline__ void render_tile_part(SceneRef S, const RenderArgs &a, int local, int part, WaveStack &stk,
-                                                 const float *grid_off, float *tap_lds, float *rgb_tiles, uint8_t *rgb8_tiles, Work &wk) {
+                                                 const float *grid_off, float *rgb_tiles, uint8_t *rgb8_tiles, Work &wk) {
+    float *tap_lds = split_tap_lds<F>(stk);
     constexpr int PX = 64 / PH;  // pixels of a block
     const int quad = part / PH, sub = part % PH;
     const int tile = shard_tile(local, a.rank, a.world_size);
@@ -547,11 +562,12 @@ __device__ __forceinline__ void render_tile_part(SceneRef S, const RenderArgs &a
     bool inside = tile < a.tiles_total && i < a.width && j < a.height;
     const int taps = taps_of(a.mode, a.grid_m);
     const int slot = wave * PH + phase;  // one of the block's 4 * PH tap slots
+    stk.cold_put(cold_slots(F), pixel_dx(a.cam, i)); stk.cold_put(cold_slots(F) + 1, pixel_dy(a.cam, j));
     v3 color = V3(0, 0, 0);
     for (int base = 0; base < taps; base += kRoundTaps) {
         int n = taps - base < kRoundTaps ? taps - base : kRoundTaps, chunk = (n + 4 * PH - 1) / (4 * PH);
-        TapSlice src;
-        src.cam = a.cam; src.mode = a.mode; src.grid_m = a.grid_m; src.dx = pixel_dx(a.cam, i); src.dy = pixel_dy(a.cam, j); src.base = base; src.wt = 1.0f;
+        TapSlice<cold_slots(F)> src;
+        src.cam = a.cam; src.mode = a.mode; src.grid_m = a.grid_m; src.stk = &stk; src.base = base; src.wt = 1.0f;
         src.k = base + (slot * chunk < n ? slot * chunk : n);
         src.k_end = base + ((slot + 1) * chunk < n ? (slot + 1) * chunk : n);
         src.col = src.k % a.grid_m; src.row = src.k / a.grid_m; src.grid_off = grid_off;  // (one division per round, not per tap)
@@ -588,13 +604,12 @@ __global__ __launch_bounds__(kBlock, split_waves(F, COUNT)) void k_render_split(
                                                                                  uint8_t *rgb8_tiles, unsigned long long *counters) {
     SceneRef S = scene_ref(scene);
     unbundle(a);
-    RT_WAVE_STACK(stk, F, false);
-    __shared__ float tap_lds[kRoundTaps * 3 * (64 / PH)];
+    RT_WAVE_STACK(stk, F, kSplitSlots);
     __shared__ float s_grid_off[kMaxGrid];
     fill_grid_table(s_grid_off, a);
     Work wk;
     work_zero(wk);
-    render_tile_part<F, COUNT, PH>(S, a, blockIdx.x / (4 * PH), blockIdx.x % (4 * PH), stk, s_grid_off, tap_lds, rgb_tiles, rgb8_tiles, wk);
+    render_tile_part<F, COUNT, PH>(S, a, blockIdx.x / (4 * PH), blockIdx.x % (4 * PH), stk, s_grid_off, rgb_tiles, rgb8_tiles, wk);
     flush_work(wk, counters, COUNT);
 }
 
@@ -619,14 +634,13 @@ __global__ __launch_bounds__(kBlock, split_waves(F, false)) void k_render_hybrid
     if (!heavy && quad != worker) return;
     const unsigned long long t0 = wall_clock64();
     unbundle(a);
-    RT_WAVE_STACK(stk, F, false);
-    __shared__ float tap_lds[kRoundTaps * 3 * 64];
+    RT_WAVE_STACK(stk, F, kSplitSlots);
     __shared__ float s_grid_off[kMaxGrid];
     fill_grid_table(s_grid_off, a);
     Work wk;
     work_zero(wk);
-    if (heavy) render_tile_part<F, false, 1>(S, a, local, quad, stk, s_grid_off, tap_lds, rgb_tiles, rgb8_tiles, wk);
-    else render_tile<F, false, false>(S, a, local, stk, s_grid_off, rgb_tiles, rgb8_tiles, wk);
+    if (heavy) render_tile_part<F, false, 1>(S, a, local, quad, stk, s_grid_off, rgb_tiles, rgb8_tiles, wk);
+    else render_tile<F, false, true>(S, a, local, stk, s_grid_off, rgb_tiles, rgb8_tiles, wk);
     flush_work(wk, counters, false);
     __syncthreads();
     if (threadIdx.x == 0 && quad == worker) {
@@ -760,8 +774,7 @@ __global__ __launch_bounds__(kBlock, split_waves(F, false)) void k_render_queue(
     SceneRef S = scene_ref(scene);
     QueueArgs qa = {q_hdr, q_items, q_cost_out};
     unbundle(a);
-    RT_WAVE_STACK(stk, F, false);
-    __shared__ float tap_lds[kRoundTaps * 3 * 64];
+    RT_WAVE_STACK(stk, F, kSplitSlots);
     __shared__ float s_grid_off[kMaxGrid];
     __shared__ uint32_t s_item;
     fill_grid_table(s_grid_off, a);
@@ -777,7 +790,7 @@ __global__ __launch_bounds__(kBlock, split_waves(F, false)) void k_render_queue(
         const uint32_t item = (uint32_t)__builtin_amdgcn_readfirstlane((int32_t)qa.items[at]);
         const int local = (int)(item & 0x0fffffffu);
         const unsigned long long t0 = wall_clock64();
-        render_item<F>(S, a, local, (item & kItemQuadrant) ? (int)((item >> 28) & 3u) : -1, stk, s_grid_off, tap_lds, rgb_tiles, rgb8_tiles, wk);
+        render_item<F>(S, a, local, (item & kItemQuadrant) ? (int)((item >> 28) & 3u) : -1, stk, s_grid_off, rgb_tiles, rgb8_tiles, wk);
         __syncthreads();
         if (threadIdx.x == 0) {
             unsigned long long dt = wall_clock64() - t0;
@@ -832,7 +845,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_rays(const DevScene *scene, lo
                                                        int max_depth, int accel, rt_hit_record *hits, float *radiance,
                                                        unsigned long long *counters) {
     SceneRef S = scene_ref(scene);
-    RT_WAVE_STACK(stk, F_ALL, false);
+    RT_WAVE_STACK(stk, F_ALL, 0);
     long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     Work wk;
     work_zero(wk);
@@ -848,7 +861,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_rays(const DevScene *scene, lo
 __global__ __launch_bounds__(kBlock) void k_intersect_object(const DevScene *scene, int object, long long n, const float *o,
                                                              const float *d, int accel, rt_hit_record *hits) {
     SceneRef S = scene_ref(scene);
-    RT_WAVE_STACK(stk, F_ALL, false);
+    RT_WAVE_STACK(stk, F_ALL, 0);
     long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n) return;
     Work wk;
