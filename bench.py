@@ -9,8 +9,10 @@ row-major frame on every rank.  The frame is what the reference produces: 8-bit 
 and quantisation (main.cpp:1184-1189, Image.cpp:35-39); --float-frame also delivers the linear float
 frame (4x the bytes through the kernel's stores, the all-gather and the de-interleave).  Scene, LBVH and output buffers are resident in HBM before the
 timed region.  Rank 0 prints one JSON line: metric = Mrays/s where one ray is one closest-hit
-query (primary, shadow, reflection, refraction alike), plus the roofline of the trace kernel and
-a CPU baseline (the oracle restatement of the reference's brute-force loop, timed on a sample).
+query that was executed (primary, shadow, reflection, refraction alike); the reference's own ray
+count, which also has the shadow rays that were answered without a query, is printed beside it
+(rays.answered_*).  Plus the roofline of the trace kernel and a CPU baseline (the oracle
+restatement of the reference's brute-force loop, timed on a sample).
 """
 import argparse
 import json
@@ -240,7 +242,8 @@ def main():
         elapsed = float(rows[:, 0].max())  # the slowest rank decides
         rays_total, shadow_queries = float(rows[:, 2].sum()), float(rows[:, 3].sum())
         ms_per_step = elapsed / args.steps * 1e3
-        value = rays_total / elapsed / 1e6
+        executed_total = float(rows[:, 7 + len(count_names)].sum())
+        value = executed_total / elapsed / 1e6
         # roofline of the render kernel: algorithmic flops of each rank's launch over that launch's duration, per GPU
         per_rank_tflops = [float(r[4]) / (float(r[1]) * 1e-3) / 1e12 if r[1] > 0 else 0.0 for r in rows]
         achieved_tflops = sum(per_rank_tflops) / world
@@ -251,7 +254,7 @@ def main():
         counts["node_steps_waves"] = int(rows[:, 8 + len(count_names)].sum())
         node_lane_visits = float(rows[:, 9 + len(count_names)].sum())
         kernel_ms_max = float(rows[:, 1].max())
-        traffic = pmc_flops = None
+        traffic = pmc_flops = traffic_source = fetch_bytes = None
         pmc_path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         kernel_names = ("k_render", "k_render_split<1>", "k_render_split<2>", "k_render_hybrid", "k_render_queue")
         # the counter passes were made on the single-GPU launch: no figure for a rank's share
@@ -259,28 +262,38 @@ def main():
             try:
                 rec = json.load(open(pmc_path)).get(args.workload)
                 if isinstance(rec, dict) and rec.get("kernel") == kernel_names[c.render_variant]:
-                    traffic, pmc_flops = rec.get("hbm_bytes"), rec.get("fp32_flops")
+                    traffic, pmc_flops, fetch_bytes = rec.get("hbm_bytes"), rec.get("fp32_flops"), rec.get("fetch_bytes")
+                    # (recorded rocprofv3 --pmc passes of this workload and kernel, not counters read during this run)
+                    traffic_source = "profiles/hbm_traffic.json <- profiles/" + str(rec.get("source"))
             except Exception:
-                traffic = pmc_flops = None
+                traffic = pmc_flops = traffic_source = fetch_bytes = None
         out = {
-            "metric": "Mrays/s (teapot.obj, 3840x2160, 16 spp)" if args.workload == "teapot_4k_16spp" else f"Mrays/s ({args.workload})",
+            "metric": ("Mrays/s (teapot.obj, 3840x2160, 16 spp)" if args.workload == "teapot_4k_16spp" else f"Mrays/s ({args.workload})") +
+                      "; a ray = an executed closest-hit query",
             "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "ms_per_frame": ms_per_step, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             # one ray = one find_closest_hit of the reference (main.cpp:653, 718); a shadow ray whose query the kernel
             # proved unnecessary (nothing can lie between the point and the light) is counted but was not traced
-            "rays": {"per_frame": rays_total / args.steps, "shadow_queries_executed_per_frame": shadow_queries / args.steps,
-                     "executed_Mrays_per_s": float(rows[:, 7 + len(count_names)].sum()) / elapsed / 1e6},
+            # `value` counts executed queries only; answered_* also count the shadow rays decided without one
+            "rays": {"executed_per_frame": executed_total / args.steps, "executed_Mrays_per_s": value,
+                     "answered_per_frame": rays_total / args.steps, "answered_Mrays_per_s": rays_total / elapsed / 1e6,
+                     "shadow_queries_executed_per_frame": shadow_queries / args.steps},
             "config": {"workload": args.workload, "preset": preset, "width": width, "height": height,
                        "samples_per_pixel": 1 if mode == 0 else 9 if mode == 1 else grid_m * grid_m,
                        "max_depth": max_depth, "accel": args.accel, "tiles": total_tiles,
                        "frame": "rgb8+f32" if ff else "rgb8",
-                       "parallelism": f"tiles{world}", "rays_per_frame": rays_total / args.steps,
+                       "parallelism": f"tiles{world}", "rays_per_frame": executed_total / args.steps,
                        "bvh_height": c.bvh_max_depth, "lbvh_build_ms": c.last_build_ms,
                        "tree_build": "radix" if os.environ.get("RT_BUILD") == "radix" else "binned surface-area splits",
                        "render_kernel": kernel_names[c.render_variant]},
             "roofline": {"bound": "valu", "achieved": achieved_tflops, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved_tflops / PEAK_FP32_TFLOPS, "traffic": traffic, "pmc_flops": pmc_flops,
+                         "traffic_source": traffic_source, "pmc_source": traffic_source,
+                         # tree, triangle and texture fetches through the L2 (TCC) against the HBM peak
+                         "fetch_GBps": (fetch_bytes / (kernel_ms_max * 1e-3) / 1e9) if fetch_bytes and kernel_ms_max > 0 else None,
+                         "hbm_GBps": (traffic / (kernel_ms_max * 1e-3) / 1e9) if traffic and kernel_ms_max > 0 else None,
+                         "hbm_peak_GBps": 8000.0,
                          "kernel": kernel_names[c.render_variant], "kernel_ms": kernel_ms_max,
                          "kernel_ms_per_rank": [float(x) for x in rows[:, 1]],
                          "achieved_per_rank": per_rank_tflops,

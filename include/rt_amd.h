@@ -237,14 +237,16 @@ int rt_render(rt_ctx *ctx, const rt_render_params *p, float *rgb_linear, uint8_t
 int rt_shard_tiles(const rt_render_params *p, int32_t *tiles_per_rank, int32_t *tiles_total);
 int rt_render_shard_device(rt_ctx *ctx, const rt_render_params *p, float *d_rgb_tiles,
                            uint8_t *d_rgb8_tiles);
-/* The same for callers that cannot allocate device memory (code under HIP graph capture, tight serving
- * loops, harnesses that forbid hipMalloc): no counterpart in the reference.  It always renders with the
- * RT_KERNEL_PER_TILE kernel and keeps that kernel's per-tile times in a static device array of the
- * library (520 KiB per GPU) instead of memory allocated on demand, and calls no allocating routine.
- * Limit: at most 65536 tiles (16x16 pixels each) per launch, e.g. 4096 x 4096 pixels on one GPU;
- * RT_ERR_LIMIT beyond that.  count_work is not supported.  All contexts of a GPU share the array:
- * calls that overlap on one GPU race on the tile times (the pixels are the same whatever the times
- * hold, but the tile times are then of no use to the next frame). */
+/* The same for callers that cannot allocate device memory (tight serving loops, harnesses that forbid
+ * hipMalloc): no counterpart in the reference.  It always renders with the RT_KERNEL_PER_TILE kernel and
+ * keeps that kernel's per-tile times in a static device array of the library (520 KiB per GPU) instead of
+ * memory allocated on demand, and calls no allocating routine.  Limit: at most 65536 tiles (16x16 pixels
+ * each) per launch, e.g. 4096 x 4096 pixels on one GPU; RT_ERR_LIMIT beyond that.  count_work is not
+ * supported.  All contexts of a GPU share the array, so launches through this entry point run one after
+ * the other on that GPU, whatever streams their contexts use (each waits for an event the one before
+ * recorded); contexts that alternate frames of different sizes or scenes find no usable tile times and
+ * render every tile the slower, split way, with the same pixels.  Not meant for HIP graph capture: the
+ * captured launches would keep replaying the tile times of the frame they were captured with. */
 int rt_render_shard_device_noalloc(rt_ctx *ctx, const rt_render_params *p, float *d_rgb_tiles,
                                    uint8_t *d_rgb8_tiles);
 /* De-interleaves gathered shards ([rank][local_tile][16][16][3], rank-major as all_gather delivers

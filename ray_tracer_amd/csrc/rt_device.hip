@@ -16,6 +16,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -887,6 +889,7 @@ struct TileMem {
     bool valid = false;
 };
 
+constexpr int kBuildStreams = 4;
 struct rt_ctx {
     int device = 0;
     hipStream_t stream = nullptr;      // the stream in use
@@ -925,11 +928,13 @@ struct rt_ctx {
     bool radix_tree = false;    // RT_BUILD=radix: the Morton radix tree instead of the surface-area splits
     int split_phases = 1;  // RT_SPLIT_PHASES: which split kernel RT_SPLIT_MIN_TAPS selects
     TileMem tiles;              // tile times (and the queue's item list) of this context's launches
-    unsigned scene_serial = 0;  // counts scene uploads and updates: tile times of another scene are not used
+    unsigned scene_serial = 0;  // counts scene uploads: tile times of another scene are not used (rt_scene_update keeps them: a pose changes little from one frame to the next, and they only decide who renders a tile)
     int queue_slots[16] = {0};  // resident blocks of k_render_queue<features> on this device, by feature set (0: not asked yet)
     int forced_variant = -1;          // RT_RENDER_VARIANT: this kernel for every frame (tests)
     long long forced_threshold = -1;  // RT_HYBRID_THRESHOLD: ticks of 10 ns above which a tile counts as heavy (tests)
     int last_variant = 0;
+    hipStream_t build_stream[kBuildStreams] = {nullptr, nullptr, nullptr, nullptr};  // rt_build_accel: meshes side by side
+    hipEvent_t build_done[kBuildStreams] = {nullptr, nullptr, nullptr, nullptr}, build_fork = nullptr;
 };
 
 #define RT_HIP(call)                                                                             \
@@ -1016,6 +1021,11 @@ extern "C" int rt_context_destroy(rt_ctx *ctx) {
     (void)hipFree(ctx->tiles.hdr);
     (void)hipEventDestroy(ctx->ev0);
     (void)hipEventDestroy(ctx->ev1);
+    for (int k = 0; k < kBuildStreams; k++) {
+        if (ctx->build_done[k]) (void)hipEventDestroy(ctx->build_done[k]);
+        if (ctx->build_stream[k]) (void)hipStreamDestroy(ctx->build_stream[k]);
+    }
+    if (ctx->build_fork) (void)hipEventDestroy(ctx->build_fork);
     (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return RT_OK;
@@ -1272,10 +1282,21 @@ extern "C" int rt_build_accel(rt_ctx *ctx) {
     if (!ctx->uploaded) return fail(ctx, RT_ERR_STATE, "rt_build_accel before rt_scene_upload");
     if (ctx->built) return RT_OK;
     RT_HIP(hipSetDevice(ctx->device));
+    // The meshes are built side by side: each on one of a few streams, with a slice of every work array to itself.
+    // A build is a chain of some twenty-five small dependent launches (its first tree levels are single blocks), so
+    // one mesh leaves most of the GPU idle and several of them cost little more than the largest alone.
+    const size_t n_meshes = ctx->meshes.size();
     int max_n = 0;
-    for (const DevMesh &m : ctx->meshes) max_n = std::max(max_n, m.tri_count);
-    int max_pow2 = kSortChunk;  // the sort works on whole chunks
-    while (max_pow2 < max_n) max_pow2 <<= 1;
+    size_t sum_n = 0, sum_pow2 = 0;
+    std::vector<size_t> at_n(n_meshes + 1, 0), at_pow2(n_meshes + 1, 0);  // where each mesh's slices start
+    for (size_t i = 0; i < n_meshes; i++) {
+        const int n = std::max(ctx->meshes[i].tri_count, 0);
+        int n_pow2 = kSortChunk;  // the sort works on whole chunks
+        while (n_pow2 < n) n_pow2 <<= 1;
+        max_n = std::max(max_n, n);
+        at_n[i] = sum_n; at_pow2[i] = sum_pow2;
+        sum_n += (size_t)n; sum_pow2 += (size_t)n_pow2;
+    }
     int max_levels = 2;         // height of the top-down tree: kSahDepthLimit + log2(n) at most (rt_lbvh.h)
     for (int v = 1; v < max_n; v <<= 1) max_levels++;
     max_levels += kSahDepthLimit;
@@ -1284,30 +1305,29 @@ extern "C" int rt_build_accel(rt_ctx *ctx) {
     float *d_lo = nullptr, *d_hi = nullptr, *d_bounds = nullptr;
     int32_t *d_idx[2] = {nullptr, nullptr}, *d_level_jobs = nullptr, *d_node_parent = nullptr, *d_leaf_parent = nullptr;
     SahJob *d_jobs[2] = {nullptr, nullptr};
-    const size_t n_meshes = ctx->meshes.size();
     int rc;
     std::vector<void *> tmp;
     auto cleanup = [&]() { for (void *p : tmp) (void)hipFree(p); };
 #define TMP_ALLOC(ptr, count)                                                    \
     if ((rc = dev_alloc(ctx, &ptr, (count), (const void *)nullptr, false))) { cleanup(); return rc; } \
     tmp.push_back(ptr)
-    TMP_ALLOC(d_keys, (size_t)max_pow2);
-    TMP_ALLOC(d_c0, (size_t)max_n);
-    TMP_ALLOC(d_c1, (size_t)max_n);
-    TMP_ALLOC(d_done, (size_t)max_n);
-    TMP_ALLOC(d_height, (size_t)max_n);
-    TMP_ALLOC(d_node_parent, (size_t)max_n);
-    TMP_ALLOC(d_leaf_parent, (size_t)max_n);
+    TMP_ALLOC(d_keys, sum_pow2);
+    TMP_ALLOC(d_c0, sum_n);
+    TMP_ALLOC(d_c1, sum_n);
+    TMP_ALLOC(d_done, sum_n);
+    TMP_ALLOC(d_height, sum_n);
+    TMP_ALLOC(d_node_parent, sum_n);
+    TMP_ALLOC(d_leaf_parent, sum_n);
     TMP_ALLOC(d_root, n_meshes + 1);
     TMP_ALLOC(d_root_id, n_meshes + 1);
-    TMP_ALLOC(d_lo, 3 * (size_t)max_n);
-    TMP_ALLOC(d_hi, 3 * (size_t)max_n);
+    TMP_ALLOC(d_lo, 3 * sum_n);
+    TMP_ALLOC(d_hi, 3 * sum_n);
     TMP_ALLOC(d_bounds, 6 * n_meshes + 6);
     if (!ctx->radix_tree) {
-        TMP_ALLOC(d_idx[0], (size_t)max_n);
-        TMP_ALLOC(d_idx[1], (size_t)max_n);
-        TMP_ALLOC(d_jobs[0], (size_t)max_n);
-        TMP_ALLOC(d_jobs[1], (size_t)max_n);
+        TMP_ALLOC(d_idx[0], sum_n);
+        TMP_ALLOC(d_idx[1], sum_n);
+        TMP_ALLOC(d_jobs[0], sum_n);
+        TMP_ALLOC(d_jobs[1], sum_n);
         TMP_ALLOC(d_level_jobs, (size_t)(max_levels + 2) * (n_meshes + 1));  // a row per mesh: the last count of each is checked at the end
     }
 #undef TMP_ALLOC
@@ -1318,34 +1338,62 @@ extern "C" int rt_build_accel(rt_ctx *ctx) {
     if (e == hipSuccess) e = hipMemsetAsync(d_root_id, 0, (n_meshes + 1) * sizeof(int32_t), ctx->stream);  // the radix tree's root is node 0
     if (e == hipSuccess) e = hipMemsetAsync(d_root, 0, (n_meshes + 1) * sizeof(int32_t), ctx->stream);
     if (e == hipSuccess && d_level_jobs) e = hipMemsetAsync(d_level_jobs, 0, (size_t)(max_levels + 2) * (n_meshes + 1) * sizeof(int32_t), ctx->stream);
+    if (e == hipSuccess && sum_n) e = hipMemsetAsync(d_done, 0, sum_n * sizeof(int32_t), ctx->stream);
+    // the side streams (kept with the context) and the events that fork them off the context's stream and join them back
+    int n_side = 0;
+    for (size_t i = 0; i < n_meshes; i++) if (ctx->meshes[i].tri_count > 0) n_side++;
+    n_side = std::min(n_side, kBuildStreams);
+    if (n_side < 2) n_side = 0;  // a single mesh is built on the context's stream
+    for (int k = 0; k < n_side && e == hipSuccess; k++) {
+        if (!ctx->build_stream[k]) e = hipStreamCreateWithFlags(&ctx->build_stream[k], hipStreamNonBlocking);
+        if (e == hipSuccess && !ctx->build_done[k]) e = hipEventCreateWithFlags(&ctx->build_done[k], hipEventDisableTiming);
+    }
+    if (e == hipSuccess && n_side && !ctx->build_fork) e = hipEventCreateWithFlags(&ctx->build_fork, hipEventDisableTiming);
     if (e != hipSuccess) { cleanup(); return fail(ctx, RT_ERR_HIP, hipGetErrorString(e)); }
 
     // Everything below is queued without waiting for the device: the number of jobs of a level stays there.
     std::vector<int> unfinished_at(n_meshes, -1);  // per mesh: the entry of its row of d_level_jobs that must still be zero at the end
     (void)hipEventRecord(ctx->ev0, ctx->stream);
+    if (n_side) {
+        (void)hipEventRecord(ctx->build_fork, ctx->stream);
+        for (int k = 0; k < n_side; k++) (void)hipStreamWaitEvent(ctx->build_stream[k], ctx->build_fork, 0);
+    }
+    // The launches of a mesh are collected first and then issued in turn, one of every mesh at a time: issued mesh by
+    // mesh, the second mesh's first kernel would wait on the host behind the forty launches of the first.
+    int turn = 0;
+    std::vector<std::vector<std::function<void()>>> ops(n_meshes);
     for (size_t i = 0; i < n_meshes; i++) {
         const DevMesh &m = ctx->meshes[i];
         int n = m.tri_count;
         if (n <= 0) continue;
+        hipStream_t st = n_side ? ctx->build_stream[turn++ % n_side] : ctx->stream;
+        std::vector<std::function<void()>> &q = ops[i];
         int n_pow2 = kSortChunk;
         while (n_pow2 < n) n_pow2 <<= 1;
+        // this mesh's slices of the work arrays
+        unsigned long long *keys = d_keys + at_pow2[i];
+        int32_t *c0 = d_c0 + at_n[i], *c1 = d_c1 + at_n[i], *done = d_done + at_n[i], *height = d_height + at_n[i];
+        int32_t *node_parent = d_node_parent + at_n[i], *leaf_parent = d_leaf_parent + at_n[i];
+        float *lo = d_lo + 3 * at_n[i], *hi = d_hi + 3 * at_n[i];
+        int32_t *idx0 = d_idx[0] ? d_idx[0] + at_n[i] : nullptr, *idx1 = d_idx[1] ? d_idx[1] + at_n[i] : nullptr;
+        SahJob *jobs[2] = {d_jobs[0] ? d_jobs[0] + at_n[i] : nullptr, d_jobs[1] ? d_jobs[1] + at_n[i] : nullptr};
         dim3 blk(256), grd((n_pow2 + 255) / 256);
-        hipLaunchKernelGGL(k_sort_keys, grd, blk, 0, ctx->stream, ctx->d_ref_pos + 9 * (size_t)m.tri_offset, n, n_pow2,
-                           d_bounds + 6 * i, d_bounds + 6 * i + 3, d_keys);
-        hipLaunchKernelGGL(k_bitonic_chunk, dim3(n_pow2 / kSortChunk), dim3(kSortThreads), 0, ctx->stream, d_keys, kSortChunk, 1);
+        q.push_back([=]() { hipLaunchKernelGGL(k_sort_keys, grd, blk, 0, st, ctx->d_ref_pos + 9 * (size_t)m.tri_offset, n, n_pow2,
+                           d_bounds + 6 * i, d_bounds + 6 * i + 3, keys); });
+        q.push_back([=]() { hipLaunchKernelGGL(k_bitonic_chunk, dim3(n_pow2 / kSortChunk), dim3(kSortThreads), 0, st, keys, kSortChunk, 1); });
         for (int k = 2 * kSortChunk; k <= n_pow2; k <<= 1) {
             for (int j = k >> 1; j >= kSortChunk; j >>= 1)
-                hipLaunchKernelGGL(k_bitonic_step, grd, blk, 0, ctx->stream, d_keys, n_pow2, j, k);
-            hipLaunchKernelGGL(k_bitonic_chunk, dim3(n_pow2 / kSortChunk), dim3(kSortThreads), 0, ctx->stream, d_keys, k, 0);
+                q.push_back([=]() { hipLaunchKernelGGL(k_bitonic_step, grd, blk, 0, st, keys, n_pow2, j, k); });
+            q.push_back([=]() { hipLaunchKernelGGL(k_bitonic_chunk, dim3(n_pow2 / kSortChunk), dim3(kSortThreads), 0, st, keys, k, 0); });
         }
         const bool top_down = !ctx->radix_tree && n >= 2;
         int32_t *level_jobs = top_down ? d_level_jobs + (size_t)(max_levels + 2) * i : nullptr;
-        hipLaunchKernelGGL(k_gather_tris, dim3((n + 255) / 256), blk, 0, ctx->stream, d_keys, n, m.tri_offset, ctx->d_ref_pos,
+        q.push_back([=]() { hipLaunchKernelGGL(k_gather_tris, dim3((n + 255) / 256), blk, 0, st, keys, n, m.tri_offset, ctx->d_ref_pos,
                            ctx->d_ref_tri, ctx->d_tri_pos, ctx->d_tri_frag, ctx->d_tri_sub, ctx->d_tri_test, ctx->d_tri_key,
-                           ctx->d_tri_orig, ctx->d_leaf_box, top_down ? d_idx[0] : nullptr, d_jobs[0], level_jobs, max_levels);
+                           ctx->d_tri_orig, ctx->d_leaf_box, top_down ? idx0 : nullptr, jobs[0], level_jobs, max_levels); });
         if (n >= 2) {
             if (ctx->radix_tree) {
-                hipLaunchKernelGGL(k_children, dim3((n + 255) / 256), blk, 0, ctx->stream, d_keys, n, d_c0, d_c1, d_node_parent, d_leaf_parent);
+                q.push_back([=]() { hipLaunchKernelGGL(k_children, dim3((n + 255) / 256), blk, 0, st, keys, n, c0, c1, node_parent, leaf_parent); });
             } else {
                 // top-down, one launch per level for the levels a balanced tree has and two more, then one launch
                 // that finishes what is left.  A level has at most min(2^level, n / 2) jobs: each covers two
@@ -1358,21 +1406,29 @@ extern "C" int rt_build_accel(rt_ctx *ctx) {
                     // a job of this level has n / 2^level leaves if the tree is balanced; no more than four per thread then
                     int waves = 1;
                     while (!finish && waves < kSahMaxWaves && (long long)waves * 256 * (1ll << std::min(level, 30)) < n) waves <<= 1;
-                    hipLaunchKernelGGL(k_sah_level, dim3((unsigned)most), dim3(64 * waves), 0, ctx->stream,
-                                       d_jobs[level & 1], level_jobs + level, ctx->d_leaf_box + 6 * (size_t)m.tri_offset, d_idx[0], d_idx[1],
-                                       d_c0, d_c1, d_node_parent, d_leaf_parent, d_jobs[(level & 1) ^ 1], d_root_id + i, finish ? 1 : 0);
+                    q.push_back([=]() { hipLaunchKernelGGL(k_sah_level, dim3((unsigned)most), dim3(64 * waves), 0, st,
+                                       jobs[level & 1], level_jobs + level, ctx->d_leaf_box + 6 * (size_t)m.tri_offset, idx0, idx1,
+                                       c0, c1, node_parent, leaf_parent, jobs[(level & 1) ^ 1], d_root_id + i, finish ? 1 : 0); });
                 }
                 unfinished_at[i] = levels + 2;
             }
-            e = hipMemsetAsync(d_done, 0, (size_t)n * sizeof(int32_t), ctx->stream);
-            if (e != hipSuccess) break;
-            hipLaunchKernelGGL(k_fit, dim3((n + 255) / 256), blk, 0, ctx->stream, n, d_c0, d_c1, d_node_parent, d_leaf_parent,
-                               ctx->d_leaf_box + 6 * (size_t)m.tri_offset, ctx->mesh_build[i].pad, d_done, d_lo, d_hi, d_height,
-                               ctx->d_nodes + m.node_offset, d_root + i);
+            q.push_back([=]() { hipLaunchKernelGGL(k_fit, dim3((n + 255) / 256), blk, 0, st, n, c0, c1, node_parent, leaf_parent,
+                               ctx->d_leaf_box + 6 * (size_t)m.tri_offset, ctx->mesh_build[i].pad, done, lo, hi, height,
+                               ctx->d_nodes + m.node_offset, d_root + i); });
             int nv = (n - 1) * (kOctants - 1);
-            hipLaunchKernelGGL(k_octant_variants, dim3((nv + 255) / 256), blk, 0, ctx->stream, ctx->d_nodes + m.node_offset, n - 1);
-            hipLaunchKernelGGL(k_octant_variant0, dim3((n - 1 + 255) / 256), blk, 0, ctx->stream, ctx->d_nodes + m.node_offset, n - 1);
+            q.push_back([=]() { hipLaunchKernelGGL(k_octant_variants, dim3((nv + 255) / 256), blk, 0, st, ctx->d_nodes + m.node_offset, n - 1); });
+            q.push_back([=]() { hipLaunchKernelGGL(k_octant_variant0, dim3((n - 1 + 255) / 256), blk, 0, st, ctx->d_nodes + m.node_offset, n - 1); });
         }
+    }
+    for (size_t step = 0;; step++) {
+        bool any = false;
+        for (size_t i = 0; i < n_meshes; i++)
+            if (step < ops[i].size()) { ops[i][step](); any = true; }
+        if (!any) break;
+    }
+    for (int k = 0; k < n_side; k++) {
+        (void)hipEventRecord(ctx->build_done[k], ctx->build_stream[k]);
+        (void)hipStreamWaitEvent(ctx->stream, ctx->build_done[k], 0);
     }
     (void)hipEventRecord(ctx->ev1, ctx->stream);
     ctx->trace_timed = false;
@@ -1463,12 +1519,21 @@ static __device__ __align__(256) unsigned char scratch[kNoAllocBytes];
 constexpr int kMaxDevices = 64;
 static TileMem g_noalloc[kMaxDevices];  // per device: the carved pointer into that device's array and what its times belong to
 static bool g_noalloc_ready[kMaxDevices];
+// All contexts of a GPU share that GPU's array, and the per-tile kernel reads one frame's tile times while it writes the
+// next frame's: two launches in flight at once would read each other's half-written times and disagree, block by
+// block, on which tiles are split.  Launches through this entry point are therefore ordered per device: each waits
+// for the event the previous one recorded (created with the array; waiting and recording allocate nothing), and the
+// host-side bookkeeping (which of the two time arrays is current, whose frame they describe) is done under a lock.
+static hipEvent_t g_noalloc_done[kMaxDevices];
+static std::mutex g_noalloc_mutex;
 
 static int noalloc_setup(rt_ctx *ctx) {  // once per device, with that device current
     if (ctx->device < 0 || ctx->device >= kMaxDevices) return RT_OK;  // (such a device gets RT_ERR_LIMIT from the entry point)
+    std::lock_guard<std::mutex> lock(g_noalloc_mutex);
     if (g_noalloc_ready[ctx->device]) return RT_OK;
     void *ptr = nullptr;
     RT_HIP(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+    RT_HIP(hipEventCreateWithFlags(&g_noalloc_done[ctx->device], hipEventDisableTiming));
     tile_mem_carve(g_noalloc[ctx->device], ptr, kNoAllocMaxTiles, false);
     g_noalloc_ready[ctx->device] = true;
     return RT_OK;
@@ -1628,8 +1693,12 @@ extern "C" int rt_render_shard_device_noalloc(rt_ctx *ctx, const rt_render_param
     if (ctx->device < 0 || ctx->device >= kMaxDevices || !g_noalloc_ready[ctx->device])
         return fail(ctx, RT_ERR_LIMIT, "no static tile memory for device " + std::to_string(ctx->device));
     RT_HIP(hipSetDevice(ctx->device));
-    // always the kernel that keeps tile times (they are what lives in the static array)
-    return render_shard(ctx, p, d_rgb_tiles, d_rgb8_tiles, g_noalloc[ctx->device], false, 3);
+    // always the kernel that keeps tile times (they are what lives in the static array); one launch after the other per device
+    std::lock_guard<std::mutex> lock(g_noalloc_mutex);
+    RT_HIP(hipStreamWaitEvent(ctx->stream, g_noalloc_done[ctx->device], 0));
+    rc = render_shard(ctx, p, d_rgb_tiles, d_rgb8_tiles, g_noalloc[ctx->device], false, 3);
+    RT_HIP(hipEventRecord(g_noalloc_done[ctx->device], ctx->stream));
+    return rc;
 }
 
 static int untile_on(rt_ctx *ctx, hipStream_t stream, const rt_render_params *p, const float *d_rgb_shards, float *d_rgb_frame,
