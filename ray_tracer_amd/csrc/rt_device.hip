@@ -1554,9 +1554,11 @@ static int queue_slots_of(rt_ctx *ctx) {
 // one after the other, and a tile on a mesh takes many times as long as the average tile: with many taps per pixel,
 // or with so few tiles that the launch is only a few such blocks long (one GPU's share of a frame on a node of
 // several), the longest blocks decide the time.  There k_render_hybrid renders the tiles that took long in the
-// previous frame with four blocks each (measured on one GPU's share of the 4K teapot frame at 2 / 4 / 8 GPUs:
-// 1.48 / 0.77 / 0.46 ms against k_render's 2.06 / 1.48 / 1.23).  Everything else goes to k_render, which has the
-// fewest instructions per ray.  rt_render_params.kernel or RT_RENDER_VARIANT name another kernel.
+// previous frame with four blocks each (measured on one GPU's share of the 4K teapot frame at 2 / 4 GPUs:
+// 1.27 / 0.67 ms against k_render's 1.9 / 1.3), and for launches of under four rounds of resident blocks (a share
+// at 8 GPUs) the persistent k_render_queue hands the heavy tiles' quadrants out first (0.39 ms against 0.42 and
+// k_render's 0.87; at 4 GPUs it loses, 0.74 against 0.67).  Everything else goes to k_render, which has the fewest
+// instructions per ray.  rt_render_params.kernel or RT_RENDER_VARIANT name another kernel.
 static int pick_variant(const rt_ctx *ctx, const rt_render_params *p, int local_tiles) {
     if (p->count_work) return 0;  // the counting instantiation is k_render's
     if (ctx->forced_variant >= 0) return ctx->forced_variant;
@@ -1564,7 +1566,9 @@ static int pick_variant(const rt_ctx *ctx, const rt_render_params *p, int local_
     const int taps = taps_of(p->mode, p->grid_m);
     if (ctx->split_forced) return taps >= ctx->split_min_taps ? ctx->split_phases : 0;
     if (!(ctx->features & F_MESH) || taps < 4) return 0;
-    const bool short_launch = local_tiles < 16 * 5 * ctx->n_cus;  // under 16 rounds of resident blocks
+    const int resident = 5 * ctx->n_cus;                      // blocks the GPU holds at a time
+    if (local_tiles < 4 * resident) return kVariantQueue;     // a very short launch (a share of a frame on a node of eight): heaviest work first
+    const bool short_launch = local_tiles < 16 * resident;    // under 16 rounds of resident blocks
     return (taps >= 32 || short_launch) ? 3 : 0;
 }
 

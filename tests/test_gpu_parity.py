@@ -439,7 +439,7 @@ def test_every_render_kernel_writes_the_same_pixels(gpu_ctx):
             rgb, rgb8 = ctx.render(333, 177, kernel=kernel, **kw)
             variants.append(ctx.counters().render_variant)
             assert np.array_equal(rgb8, ref8) and np.array_equal(rgb, ref, equal_nan=True), (kernel, variants)
-        expect = kernel - 1 if kernel != rt.KERNEL_AUTO else rt.KERNEL_PER_TILE - 1  # a mesh scene, nine taps, a short launch
+        expect = kernel - 1 if kernel != rt.KERNEL_AUTO else rt.KERNEL_QUEUE - 1  # a mesh scene, nine taps, a very short launch
         assert variants == [expect] * 4
     # scenes without meshes, and single-tap frames, go to the one-lane-per-pixel kernel
     ctx.render(96, 64, mode=rt.MODE_REF_1SPP)
