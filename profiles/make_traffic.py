@@ -26,7 +26,7 @@ rec = {
     "lanes_active": lanes,
     "valu_wave_instructions": int(g("SQ_INSTS_VALU") * scale),
     "salu_wave_instructions": int(g("SQ_INSTS_SALU") * scale),
-    "source": os.path.basename(summary),
+    "source": os.path.relpath(os.path.abspath(summary), os.path.dirname(os.path.abspath(__file__))),
 }
 path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hbm_traffic.json")
 try:

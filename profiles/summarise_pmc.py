@@ -9,7 +9,7 @@ from collections import defaultdict
 
 def main():
     root = sys.argv[1]
-    want = sys.argv[2] if len(sys.argv) > 2 else "k_render<false>"
+    want = sys.argv[2] if len(sys.argv) > 2 else "k_render<1, false>"
     out = {}
     for path in sorted(glob.glob(os.path.join(root, "*", "**", "*counter_collection.csv"), recursive=True)):
         sums, calls = defaultdict(float), defaultdict(set)
