@@ -1,7 +1,7 @@
 """What the parts of a wall sample cost, by leaving them out at run time (no special build): the teapot preset's room
 (five axis-aligned walls) with a one-triangle mesh far outside the view, so that the mesh kernel k_render<F_MESH> runs
 and every ray goes primary query -> resolve -> one shading pass per light, none with a traced shadow ray.
-Variants: 2 lights, 1 light, no light; then the teapot preset itself.  One 4K / 16-tap frame each after a warm-up frame;
+Variants: 2 lights, 1 light, no light; then the teapot preset itself, with and without its lights.  One 4K / 16-tap frame each after a warm-up frame;
 run under `rocprofv3 --pmc ...` the dispatches appear in this order (2 per variant), see profiles/run_phase_costs.sh."""
 import os, sys
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
@@ -24,9 +24,18 @@ def room(n_lights):
     return sc
 
 
-for name, sc in [("room_2_lights", room(2)), ("room_1_light", room(1)), ("room_0_lights", room(0)), ("teapot", rt.HostScene("teapot"))]:
+class teapot_without_lights:
+    """The teapot preset's scene description with the light count set to zero (the host scene stays alive with it)."""
+    def __init__(self):
+        self.scene = rt.HostScene("teapot")
+        self.desc = self.scene.flatten()
+        self.desc.contents.n_lights = 0
+
+
+for name, sc in [("room_2_lights", room(2)), ("room_1_light", room(1)), ("room_0_lights", room(0)), ("teapot", rt.HostScene("teapot")),
+                 ("teapot_0_lights", teapot_without_lights())]:
     ctx = rt.Context(0)
-    ctx.upload(sc)
+    ctx.upload(sc.desc if isinstance(sc, teapot_without_lights) else sc)
     ts = []
     for _ in range(2):
         ctx.render(3840, 2160, want_rgb=False, want_rgb8=True, mode=rt.MODE_GRID, grid_m=4, kernel=rt.KERNEL_PIXEL)

@@ -4,7 +4,7 @@ import csv, glob, os, sys
 from collections import defaultdict
 
 root = sys.argv[1]
-names = ["room_2_lights", "room_1_light", "room_0_lights", "teapot"]
+names = ["room_2_lights", "room_1_light", "room_0_lights", "teapot", "teapot_0_lights"]
 vals = defaultdict(dict)  # variant -> counter -> per wave-sample
 for path in sorted(glob.glob(os.path.join(root, "*", "**", "*counter_collection.csv"), recursive=True)):
     rows = [r for r in csv.DictReader(open(path)) if "k_render" in r["Kernel_Name"]]
