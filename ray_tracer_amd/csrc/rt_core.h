@@ -107,6 +107,12 @@ RT_HD int32_t wave_uniform(int32_t v) {  // the value of the first active lane, 
 // uniform u = wave_uniform(mine) must go on using u (a scalar register: addresses formed from it give scalar loads);
 // an optimiser that knows the two are equal there is free to substitute the per-lane value.  Comparing with
 // uniform_alias(u) instead keeps u itself out of the equality.
+RT_HD uint64_t uniform_alias64(uint64_t u) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("" : "+s"(u));
+#endif
+    return u;
+}
 RT_HD int32_t uniform_alias(int32_t u) {
 #if defined(__HIP_DEVICE_COMPILE__)
     asm("" : "+s"(u));
@@ -180,6 +186,11 @@ RT_HD float u2f(uint32_t u) {
     float f; memcpy(&f, &u, 4); return f;
 #endif
 }
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RT_UNREACHABLE() __builtin_unreachable()
+#else
+#define RT_UNREACHABLE() ((void)0)
+#endif
 RT_HD bool has_nan(v3 a) { return !(a.x == a.x) || !(a.y == a.y) || !(a.z == a.z); }
 
 // mat4 * vec4 of glm/detail/type_mat4x4.inl:561-572 on a matrix stored as four 3-row columns:
@@ -236,12 +247,14 @@ struct alignas(64) LightCull { f4 cone[kCullMeshes]; };
 // Everything the light loop reads of one light, 128 bytes: two scalar loads at a known place (Light, main.cpp:553-559,
 // plus the cones of its LightCull).
 struct alignas(64) LightRec {
-    float pos[3], pad0;
+    float pos[3];
+    uint32_t flags;  // kLightCullable
     float color[3], pad1;
     uint32_t pad2[8];
     LightCull cull;
 };
 static_assert(sizeof(LightRec) == 128, "LightRec layout");
+constexpr uint32_t kLightCullable = 1u;  // LightRec::flags: the cones decide alone whether a shadow query towards this light is needed
 constexpr uint32_t kUnusedCone = 0x40000000u;  // cos = 2.0f: the slot of a mesh that is not there
 struct BvhNode {
     float lo0[3], hi0[3];
@@ -387,10 +400,14 @@ struct alignas(64) DevScene {
     // ---- lights
     int32_t n_lights;
     uint32_t cullable_lights;       // bit l: the cones of light l decide alone whether a shadow query is needed (l < 32)
-    const LightRec *light_recs;     // all lights (the first kEmbLights also in light_first)
+    const void *unused_lights;      // (keeps the layout)
     uint32_t pad1[12];
+    // The records of ALL lights: the scene record is allocated with room for max(n_lights, kEmbLights) of them, so light
+    // l is at a fixed offset from the record's own address (no table pointer to load, no case to tell apart).
     LightRec light_first[kEmbLights];
 };
+// bytes of a scene record for a scene of n_lights lights
+RT_HD size_t scene_record_bytes(int32_t n_lights) { return sizeof(DevScene) + (size_t)(n_lights > kEmbLights ? n_lights - kEmbLights : 0) * sizeof(LightRec); }
 // How the per-ray code sees the scene: a reference to the record in device memory, read through the constant
 // address space (always scalar loads).  The kernels receive its address, two scalar registers, instead of the
 // record itself: sixty-odd kernel-argument registers that stayed live through every loop pushed as many other
@@ -433,9 +450,8 @@ RT_HD const char *obj_rec_at(SceneRef S, int32_t i, float with) {
     if (i < kEmbObjects) return (const char *)(uintptr_t)&S.obj_first[i];
     return (const char *)(fresh(S, with).obj_recs + i);
 }
-RT_HD const char *light_rec_at(SceneRef S, int32_t i, float with) {
-    if (i < kEmbLights) return (const char *)(uintptr_t)&S.light_first[i];
-    return (const char *)(fresh(S, with).light_recs + i);
+RT_HD const char *light_rec_at(SceneRef S, int32_t i) {
+    return (const char *)(uintptr_t)&S.light_first[0] + (size_t)i * sizeof(LightRec);
 }
 
 // per-thread work counters; the counting variant is a separate template instantiation
@@ -759,6 +775,17 @@ RT_HD bool slab(const float *lo, const float *hi, v3 o, v3 inv, float tmax, floa
 }
 
 RT_HD float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+// fminf(a, b) for a b that is known not to be a signalling NaN but not known so to the compiler, which would first pass
+// it through an instruction that quiets it
+RT_HD float fmin_plain(float a, float b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+#else
+    return fminf(a, b);
+#endif
+}
 // Reciprocal for the conservative box tests only (never for a hit decision): 1-ulp hardware rcp on
 // the GPU; a zero component becomes a huge finite value so that the fused slab test cannot produce
 // inf - inf.
@@ -830,9 +857,9 @@ RT_HD void bvh_walk(const BvhNode *nodes, const f4 *tt, const uint32_t *keys, in
             uint64_t b0, b1;
             if (ONE_OCTANT) {
                 float n0 = fmaxf(fmaxf(fma_(u2f(nd[0]), inv.x, -oi.x), fma_(u2f(nd[1]), inv.y, -oi.y)), fmaxf(fma_(u2f(nd[2]), inv.z, -oi.z), 0.0f));
-                float f0 = fminf(fminf(fma_(u2f(nd[3]), inv.x, -oi.x), fma_(u2f(nd[4]), inv.y, -oi.y)), fminf(fma_(u2f(nd[5]), inv.z, -oi.z), tm));
+                float f0 = fminf(fminf(fma_(u2f(nd[3]), inv.x, -oi.x), fma_(u2f(nd[4]), inv.y, -oi.y)), fmin_plain(fma_(u2f(nd[5]), inv.z, -oi.z), tm));
                 float n1 = fmaxf(fmaxf(fma_(u2f(nd[6]), inv.x, -oi.x), fma_(u2f(nd[7]), inv.y, -oi.y)), fmaxf(fma_(u2f(nd[8]), inv.z, -oi.z), 0.0f));
-                float f1 = fminf(fminf(fma_(u2f(nd[9]), inv.x, -oi.x), fma_(u2f(nd[10]), inv.y, -oi.y)), fminf(fma_(u2f(nd[11]), inv.z, -oi.z), tm));
+                float f1 = fminf(fminf(fma_(u2f(nd[9]), inv.x, -oi.x), fma_(u2f(nd[10]), inv.y, -oi.y)), fmin_plain(fma_(u2f(nd[11]), inv.z, -oi.z), tm));
                 b0 = wave_ballot(n0 <= f0); b1 = wave_ballot(n1 <= f1);
             } else {
                 float n0, n1;
@@ -840,13 +867,16 @@ RT_HD void bvh_walk(const BvhNode *nodes, const f4 *tt, const uint32_t *keys, in
                 bool h1 = slab_fused(u2f(nd[6]), u2f(nd[7]), u2f(nd[8]), u2f(nd[9]), u2f(nd[10]), u2f(nd[11]), inv, oi, tm, n1);
                 b0 = wave_ballot(h0); b1 = wave_ballot(h1);
             }
+            // (the second child's mask is tested at two places; through an alias the second test is a scalar compare of
+            // its own: a condition shared between blocks is kept as a lane mask and inverted by two vector instructions)
             if (b0 != 0) {
                 if (b1 != 0) stk.put(sp++, (int32_t)nd[13], b1);
                 cur = (int32_t)nd[12]; inm = b0;
                 continue;
             }
-            if (b1 != 0) {
-                cur = (int32_t)nd[13]; inm = b1;
+            const uint64_t b1_alone = uniform_alias64(b1);
+            if (b1_alone != 0) {
+                cur = (int32_t)nd[13]; inm = b1_alone;
                 continue;
             }
         } else {
@@ -867,10 +897,9 @@ RT_HD void bvh_walk(const BvhNode *nodes, const f4 *tt, const uint32_t *keys, in
 // within its current best t, exactly the triangles a private traversal would test, so the result
 // is identical to the reference's linear scan.  Rays of one wave come from one 8x8 pixel block (or
 // its shadow / bounce rays) and share most of their path through the tree.
-// `want`: this lane's ray takes part.  Stack: put(slot, node, mask) / get(slot, node, mask).
+// `wants`: the lanes whose rays take part (a wave-uniform mask).  Stack: put(slot, node, mask) / get(slot, node, mask).
 template <bool COUNT, class Stack>
-RT_HD void bvh_closest_packet(SceneRef S, const MeshHead &m, v3 o, v3 d, bool want, TriBest &best, Stack &stk, Work &wk) {
-    const uint64_t wants = wave_ballot(want);
+RT_HD void bvh_closest_packet(SceneRef S, const MeshHead &m, v3 o, v3 d, uint64_t wants, TriBest &best, Stack &stk, Work &wk) {
     if (wants == 0) return;
     const BvhNode *nodes = S.nodes + m.node_offset;
     const f4 *tt = S.tri_test + 3 * (size_t)m.tri_offset;
@@ -883,11 +912,12 @@ RT_HD void bvh_closest_packet(SceneRef S, const MeshHead &m, v3 o, v3 d, bool wa
     // is a wave-uniform fact: the wave reads the node variant stored for that octant and the per-lane
     // min / max pairs of the slab test disappear (same values, same decisions: t(lo) <= t(hi) for a
     // positive reciprocal, the reverse for a negative one).
-    uint64_t negx = wave_ballot(want & (inv.x < 0)), negy = wave_ballot(want & (inv.y < 0)), negz = wave_ballot(want & (inv.z < 0));
-    const bool one_octant = (negx == 0 || negx == wants) & (negy == 0 || negy == wants) & (negz == 0 || negz == wants);
+    const uint64_t negx = wave_ballot(inv.x < 0) & wants, negy = wave_ballot(inv.y < 0) & wants, negz = wave_ballot(inv.z < 0) & wants;
+    // per axis: 0 all positive, 1 all negative, 2 mixed (plain integers: conditions kept as such become lane masks)
+    const int32_t sx = negx == 0 ? 0 : negx == wants ? 1 : 2, sy = negy == 0 ? 0 : negy == wants ? 1 : 2, sz = negz == 0 ? 0 : negz == wants ? 1 : 2;
     const int32_t start = m.tri_count == 1 ? ~0 : m.root;
-    if (one_octant) {
-        nodes += (size_t)((negx != 0 ? 1 : 0) | (negy != 0 ? 2 : 0) | (negz != 0 ? 4 : 0)) * (size_t)(m.tri_count - 1);
+    if ((sx | sy | sz) < 2) {
+        nodes += (size_t)(sx | (sy << 1) | (sz << 2)) * (size_t)(m.tri_count - 1);
         bvh_walk<COUNT, true>(nodes, tt, keys, start, o, d, inv, oi, wants, best, stk, wk);
     } else {
         bvh_walk<COUNT, false>(nodes, tt, keys, start, o, d, inv, oi, wants, best, stk, wk);
@@ -914,13 +944,15 @@ struct MeshHit {
 // first and the 12 exact triangle tests run only for rays that found a triangle (the gate is a
 // conjunct of the result, so the order does not matter).
 template <bool COUNT, bool ENTRY_FIRST, class Stack>
-RT_HD bool mesh_geom(SceneRef S, const MeshHead &h, const DevMesh &m, v3 ro, v3 rd, v3 winv, v3 woi, bool want, int accel, float clip, MeshHit &mh, Stack &stk, Work &wk) {
+RT_HD bool mesh_geom(SceneRef S, const MeshHead &h, const DevMesh &m, v3 ro, v3 rd, v3 winv, v3 woi, uint64_t want, int accel, float clip, MeshHit &mh, Stack &stk, Work &wk) {
+    // want: the lanes whose rays take part, a wave-uniform mask (every test below is one comparison whose lane mask is
+    // combined with it by scalar instructions)
     // phase 1, per lane: cheap rejections
     float tn;
-    if (COUNT && want) wk.box++;
-    want = want & (h.tri_count > 0) &
-           slab_fused(h.world_lo[0], h.world_lo[1], h.world_lo[2], h.world_hi[0], h.world_hi[1], h.world_hi[2], winv, woi, INFINITY, tn);
-    if (wave_ballot(want) == 0) return false;  // the whole wave misses the mesh's world box
+    if (COUNT && wave_mask_bit(want)) wk.box++;
+    if (h.tri_count <= 0) return false;
+    want &= wave_ballot(slab_fused(h.world_lo[0], h.world_lo[1], h.world_lo[2], h.world_hi[0], h.world_hi[1], h.world_hi[2], winv, woi, INFINITY, tn));
+    if (want == 0) return false;  // the whole wave misses the mesh's world box
     v3 d = xform_dir(m.to_local, rd);
     v3 o = xform_point(m.to_local, ro);
     {   // evaluated for every mesh (no branch, so that to_local and the boxes arrive in one batch of loads);
@@ -930,19 +962,18 @@ RT_HD bool mesh_geom(SceneRef S, const MeshHead &h, const DevMesh &m, v3 ro, v3 
             bd = xform_dir(m.box_to_local, rd);
             bo = xform_point(m.box_to_local, ro);
         }
-        bool boxed = h.boxed != 0;
         v3 binv = V3(safe_rcp(bd.x), safe_rcp(bd.y), safe_rcp(bd.z));
-        if (COUNT && want && boxed) wk.box++;
-        bool g = slab_fused(m.gate_lo[0], m.gate_lo[1], m.gate_lo[2], m.gate_hi[0], m.gate_hi[1], m.gate_hi[2], binv, bo * binv, INFINITY, tn);
-        bool inside = (bo.x > m.gate_in_lo[0]) & (bo.x < m.gate_in_hi[0]) & (bo.y > m.gate_in_lo[1]) & (bo.y < m.gate_in_hi[1]) &
-                      (bo.z > m.gate_in_lo[2]) & (bo.z < m.gate_in_hi[2]);
-        want = want & (!boxed | (g & !inside));
+        if (COUNT && wave_mask_bit(want) && h.boxed != 0) wk.box++;
+        const uint64_t g = wave_ballot(slab_fused(m.gate_lo[0], m.gate_lo[1], m.gate_lo[2], m.gate_hi[0], m.gate_hi[1], m.gate_hi[2], binv, bo * binv, INFINITY, tn));
+        const uint64_t inside = wave_ballot(bo.x > m.gate_in_lo[0]) & wave_ballot(bo.x < m.gate_in_hi[0]) & wave_ballot(bo.y > m.gate_in_lo[1]) &
+                                wave_ballot(bo.y < m.gate_in_hi[1]) & wave_ballot(bo.z > m.gate_in_lo[2]) & wave_ballot(bo.z < m.gate_in_hi[2]);
+        if (h.boxed != 0) want &= g & ~inside;
     }
     // phase 2, whole wave: the tree
     TriBest best;
     best.t = clip; best.k = -1; best.key = 0xffffffffu;
     if (accel == RT_ACCEL_BRUTE) {
-        if (want) {
+        if (wave_mask_bit(want)) {
             const f4 *tt = S.tri_test + 3 * (size_t)h.tri_offset;
             const uint32_t *keys = S.tri_key + h.tri_offset;
             for (int32_t k = 0; k < h.tri_count; k++) tri_test<COUNT>(tt, k, keys[k], o, d, best, wk);
@@ -1025,9 +1056,11 @@ RT_HD float shade_rsq(float x) {
 // pow(x, y) for x in [0, 1], y >= 0 (Phong lobe, main.cpp:678)
 RT_HD float shade_pow(float x, float y) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    if (y <= 256.0f) {
-        if (y == 0.0f) return 1.0f;
-        return __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x));
+    // (one decision for the wave: the library's powf is some 150 instructions, and exponents above 256 do not occur in
+    // the reference's materials)
+    if (__builtin_amdgcn_ballot_w64(!(y <= 256.0f)) == 0) {
+        const float p = __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x));
+        return y == 0.0f ? 1.0f : p;
     }
 #endif
     return powf(x, y);
@@ -1101,7 +1134,7 @@ RT_HD void plane_axis_pair(float coord_pos, int32_t object_pos, float coord_neg,
     plane_candidate(c, q * r_a, q, d_a, object);
 }
 // words `at` .. `at + 7` of g: an AxisPair; a plane that cannot shadow the wave's light counts as absent
-RT_HD float pair_coord(uint32_t coord, uint32_t cs, uint32_t light_bit) { return (cs & light_bit) != 0 ? NAN : u2f(coord); }
+RT_HD float pair_coord(uint32_t coord, uint32_t cs, uint32_t light_bit) { return u2f((cs & light_bit) != 0 ? 0x7fc00000u : coord); }  // (a select of scalars)
 template <bool COUNT>
 RT_HD void plane_general(const u32x16 &g, int at, uint32_t light_bit, v3 ro, v3 rd, PlaneCand &c, Work &wk) {
     int32_t idx = (int32_t)g[at + 6];
@@ -1175,8 +1208,8 @@ RT_HD void planes_pass(SceneRef S, const u32x16 &g0, const u32x16 &g1, int32_t n
     const float e = c.est + nf;
     const bool has = e < INFINITY;
     // (an estimate so large that e * 1.00001f is infinite counts as unsure too: the exact quotient may not be finite)
-    const bool unsure = has & (!(c.second > e * 1.00001f) | !(t > kMinDist));
-    if (wave_ballot(unsure) != 0) {
+    const uint64_t unsure = wave_ballot(e < INFINITY) & (wave_ballot(!(c.second > e * 1.00001f)) | wave_ballot(!(t > kMinDist)));
+    if (unsure != 0) {
         planes_exact<COUNT>(S, ro, rd, best, wk);
         return;
     }
@@ -1186,10 +1219,9 @@ RT_HD void planes_pass(SceneRef S, const u32x16 &g0, const u32x16 &g1, int32_t n
 template <int F, bool COUNT, class Stack>
 RT_HD void find_closest(SceneRef scene, v3 ro, v3 rd, int accel, int light, float clip, float occl, Closest &best, Stack &stk, Work &wk) {
     SceneRef S = fresh(scene, rd.x);
-    // light: >= 0 when the ray is a shadow ray towards that light.  When all lanes of the wave are
-    // shadow rays towards the same light, planes that cannot shadow it are skipped.
-    int32_t light_u = wave_uniform(light);
-    uint32_t light_bit = (wave_ballot(light != light_u) == 0 && light_u >= 0 && light_u < 32) ? 1u << light_u : 0u;
+    // light: >= 0 when the wave's rays are shadow rays towards that light (wave-uniform: the light loop keeps the lanes
+    // of a wave in step); planes that cannot shadow it are skipped.
+    const uint32_t light_bit = (light >= 0 && light < 32) ? 1u << light : 0u;
     best.distance = INFINITY;
     best.object = -1;
     best.t = 0;
@@ -1200,7 +1232,7 @@ RT_HD void find_closest(SceneRef scene, v3 ro, v3 rd, int accel, int light, floa
     u32x16 hdr = load_u32x16((const void *)(uintptr_t)&S.planes_skip_lights);
     u32x16 g0 = load_u32x16((const void *)(uintptr_t)&S.axis_pairs[0]), g1 = load_u32x16((const void *)(uintptr_t)&S.axis_pairs[2]);
     u32x16 head0 = (F & F_MESH) ? load_u32x16((const void *)(uintptr_t)&S.mesh_heads[0]) : g0;
-    pin_scalar(hdr); pin_scalar(g0); pin_scalar(g1);
+    pin_scalar(g0); pin_scalar(g1);  // (not the head: pinned as a whole it is copied register by register to where its fields are used)
     const int32_t n_axis_overflow = (int32_t)hdr[1], n_gen_planes = (int32_t)hdr[2], n_meshes = (int32_t)hdr[3];
     const int32_t n_spheres = (int32_t)hdr[4], n_cones = (int32_t)hdr[5];
     if ((hdr[0] & light_bit) == 0)
@@ -1230,23 +1262,27 @@ RT_HD void find_closest(SceneRef scene, v3 ro, v3 rd, int accel, int light, floa
         }
     }
     if (meshes) {
-    bool nan_o = has_nan(ro), nan_d = has_nan(rd);
-    bool valid = !(nan_o | nan_d);  // every triangle test fails on NaN inputs
+    // every triangle test fails on NaN inputs (an unordered comparison finds a NaN in either operand)
+    const uint64_t valid = ~(wave_ballot(__builtin_isunordered(ro.x, ro.y)) | wave_ballot(__builtin_isunordered(ro.z, rd.x)) |
+                             wave_ballot(__builtin_isunordered(rd.y, rd.z)));
+    u32x16 next_head = head0;  // the first mesh's, from the batch of loads above; a later one is fetched when the mesh before it is done
     for (int32_t i = 0; i < n_meshes; i++) {
         // (the reciprocals per mesh, not held through the traversal of the mesh before)
         const v3 rdi = again(rd, best.distance);
         const v3 winv = V3(safe_rcp(rdi.x), safe_rcp(rdi.y), safe_rcp(rdi.z));
         const v3 woi = ro * winv;
         union { u32x16 raw; MeshHead h; } head;
-        if (i == 0) { pin_scalar(head0); head.raw = head0; }
-        else head.raw = load_u32x16(mesh_head_at(S, i, rd.y));
-        int32_t idx = head.h.object;
-        if (idx < 0) continue;  // wave-uniform
-        MeshHit mh;
-        bool want = valid & !(best.distance < occl);
-        if (mesh_geom<COUNT, (F & F_SECONDARY) != 0>(S, head.h, S.meshes[i], ro, rd, winv, woi, want, accel, clip, mh, stk, wk) && mh.from_outside && closer(mh.distance, idx, best)) {
-            best.distance = mh.distance; best.object = idx; best.t = mh.t; best.k = mh.k;
+        pin_scalar(next_head);
+        head.raw = next_head;
+        const int32_t idx = head.h.object;
+        if (idx >= 0) {  // (wave-uniform) in the object list
+            MeshHit mh;
+            const uint64_t want = valid & ~wave_ballot(best.distance < occl);
+            if (mesh_geom<COUNT, (F & F_SECONDARY) != 0>(S, head.h, S.meshes[i], ro, rd, winv, woi, want, accel, clip, mh, stk, wk) && mh.from_outside && closer(mh.distance, idx, best)) {
+                best.distance = mh.distance; best.object = idx; best.t = mh.t; best.k = mh.k;
+            }
         }
+        if (i + 1 < n_meshes) next_head = load_u32x16(mesh_head_at(S, i + 1, best.distance));
     }
     }
 }
@@ -1333,7 +1369,7 @@ RT_HD void intersect_object(SceneRef S, int32_t k, v3 ro, v3 rd, int accel, rt_h
     } else if (ob.kind == RT_OBJ_MESH) {
         MeshHit mh;
         v3 winv = V3(safe_rcp(rd.x), safe_rcp(rd.y), safe_rcp(rd.z));
-        hit = mesh_geom<COUNT, false>(S, S.meshes[ob.index], S.meshes[ob.index], ro, rd, winv, ro * winv, true, accel, INFINITY, mh, stk, wk);
+        hit = mesh_geom<COUNT, false>(S, S.meshes[ob.index], S.meshes[ob.index], ro, rd, winv, ro * winv, ~0ull, accel, INFINITY, mh, stk, wk);
         if (hit) { c.t = mh.t; c.k = mh.k; c.distance = mh.distance; from_outside = mh.from_outside; }
     } else {
         QuadricHit q;
@@ -1463,33 +1499,21 @@ RT_HD void shade_object(SceneRef S, const u32x16 &g, const u32x16 &mr, const Clo
     Mat m = mat_of(mr);
     const bool image = (F & F_TEXTURE) && mat_tex_kind(m.tex_lo) == RT_TEX_IMAGE;
     const TexRef tex = mat_tex_ref(m.tex_wh, m.tex_lo, m.tex_hi);
+    // every kind leaves its geometry in s (and a mesh with materials per triangle its lane's material in m); the shading
+    // context is then formed at one place, not once per kind with the results merged afterwards
     SurfGeo s;
     if (kind == RT_OBJ_PLANE) {
         plane_geo<COUNT>(V3(u2f(g[4]), u2f(g[5]), u2f(g[6])), V3(u2f(g[7]), u2f(g[8]), u2f(g[9])), V3(u2f(g[10]), u2f(g[11]), u2f(g[12])),
                          V3(u2f(g[13]), u2f(g[14]), u2f(g[15])), image, tex, ro, rd, c.t, s, wk);
-        shade_begin<F, COUNT>(S, m, s, rd, sc, wk);
     } else if ((F & F_MESH) && kind == RT_OBJ_MESH) {
         int32_t orig;
         mesh_geo(S, S.meshes[index], ro, rd, c.t, c.k, s, orig);
-        if ((int32_t)g[2] >= 0) {
-            shade_begin<F, COUNT>(S, m, s, rd, sc, wk);
-        } else {  // triangles with materials of their own: the same idea once more, over the materials
-            const int32_t mine = S.tri_material[orig];
-            bool left = true;
-            while (wave_ballot(left) != 0) {
-                if (left) {
-                    const int32_t mi = wave_uniform(mine);
-                    if (mine == uniform_alias(mi)) {
-                        left = false;
-                        u32x16 mr2 = load_u32x16(S.mat_recs + mi);
-                        pin_scalar(mr2);
-                        shade_begin<F, COUNT>(S, mat_of(mr2), s, rd, sc, wk);
-                    }
-                }
-            }
-        }
+        if ((int32_t)g[2] < 0)  // triangles with materials of their own: every lane reads its own
+            m = mat_of(load_u32x16_lane(S.mat_recs + S.tri_material[orig]));
     } else if (!(F & F_QUADRIC)) {
-        // unreachable: the scene has no object of another kind
+        // The scene has no object of another kind (its feature set says so, and the host checked every object's kind).
+        // Telling the compiler keeps it from carrying values "as they were" through a path nobody takes.
+        RT_UNREACHABLE();
     } else if (kind == RT_OBJ_SPHERE) {
         const rt_sphere &sp = S.spheres[index];
         QuadricHit q;
@@ -1497,7 +1521,6 @@ RT_HD void shade_object(SceneRef S, const u32x16 &g, const u32x16 &mr, const Clo
         q.t = c.t; q.cap = false; q.i = q.o + q.d * c.t;
         q.from_outside = !(fabsf(q.o.x) < 1 && fabsf(q.o.y) < 1 && fabsf(q.o.z) < 1);
         sphere_geo<COUNT>(sp, q, image, tex, s, wk);
-        shade_begin<F, COUNT>(S, m, s, rd, sc, wk);
     } else {
         const rt_cone &cn = S.cones[index];
         QuadricHit q;
@@ -1505,8 +1528,8 @@ RT_HD void shade_object(SceneRef S, const u32x16 &g, const u32x16 &mr, const Clo
         q.t = c.t; q.cap = c.k != 0; q.from_outside = true;
         q.i = select3(q.cap, q.d * c.t + q.o, q.o + q.d * c.t);
         cone_geo<COUNT>(cn, q, image, tex, s, wk);
-        shade_begin<F, COUNT>(S, m, s, rd, sc, wk);
     }
+    shade_begin<F, COUNT>(S, m, s, rd, sc, wk);
 }
 
 // From the closest hits of a wave to shading contexts.  The lanes of a wave mostly hit the same object (an 8x8
@@ -1516,12 +1539,14 @@ RT_HD void shade_object(SceneRef S, const u32x16 &g, const u32x16 &mr, const Clo
 // lanes that hit it, and repeats while lanes are left.  A lane without a hit gets a NaN point (its shadow rays miss
 // everything); its other fields are not meaningful and nobody uses them.
 template <int F, bool COUNT, class Stack>
-RT_HD void surface_shade(SceneRef scene, const Closest &c, bool hit, v3 ro, v3 rd, ShadeCtx &sc, Stack &stk, Work &wk) {
+RT_HD void surface_shade(SceneRef scene, const Closest &c, uint64_t hits, v3 ro, v3 rd, ShadeCtx &sc, Stack &stk, Work &wk) {
+    // hits: the lanes with a hit, as a wave-uniform mask.  (Predicates travel as masks formed by one comparison each and
+    // are combined by scalar instructions: a ballot of a combined condition costs two more vector instructions.)
     SceneRef S = fresh(scene, c.t);
-    const uint64_t hits = wave_ballot(hit);
+    const bool hit = wave_mask_bit(hits);
     if (hits != 0) {
         const int32_t obj = wave_value_at(c.object, hits);  // (of the first lane with a hit)
-        if (wave_ballot(hit & (c.object != uniform_alias(obj))) == 0) {
+        if ((wave_ballot(c.object != uniform_alias(obj)) & hits) == 0) {
             // one object: straight code for all lanes (a lane without a hit has c.t = 0, c.k = 0 and computes a value nobody uses)
             const char *rec = obj_rec_at(S, obj, c.distance);
             u32x16 g = load_u32x16(rec), mr = load_u32x16(rec + 64);
@@ -1545,10 +1570,11 @@ RT_HD void shade_light(ShadeCtx &sc, v3 light_color, v3 L, float r, Work &wk) {
     if (COUNT) wk.shade++;
     float NdotL = clamp01(dot(sc.normal, L));
     v3 term = sc.dc * NdotL;
-    // the view vector, the mirrored light direction and the lobe only where the material has a specular term (a
-    // zero coefficient multiplies a finite lobe value: the sum is the same without it)
-    if (sc.spec.x != 0.0f || sc.spec.y != 0.0f || sc.spec.z != 0.0f) {
-        v3 view = normalize(-sc.d_in);
+    // the view vector, the mirrored light direction and the lobe only where a material has a specular term, decided for
+    // the wave (its lanes mostly share a material; a zero coefficient multiplies a finite lobe value: the sum is the same
+    // with and without it)
+    if (wave_ballot((fabsf(sc.spec.x) + fabsf(sc.spec.y)) + fabsf(sc.spec.z) != 0.0f) != 0) {
+        v3 view = -sc.d_in * shade_rsq(dot(sc.d_in, sc.d_in));  // normalize(-d_in), colour only
         v3 R = reflect(-L, sc.normal);
         float VdotR = clamp01(dot(view, R));
         term = term + sc.spec * shade_pow(VdotR, sc.shininess);
@@ -1575,39 +1601,37 @@ RT_HD v3 shade_end(const ShadeCtx &sc) {
 // come from the hardware's 1-ulp reciprocal square root.  Which form a lane gets depends on its own ray alone, so a
 // pixel's value does not depend on which other rays share its wave.
 template <int F, bool COUNT, class Stack>
-RT_HD void shade_lights(SceneRef scene, bool hit, int accel, ShadeCtx &sc, Stack &stk, Work &wk) {
+RT_HD void shade_lights(SceneRef scene, uint64_t hits, int accel, ShadeCtx &sc, Stack &stk, Work &wk) {
+    const bool hit = wave_mask_bit(hits);
     SceneRef S0 = fresh(scene, sc.point.x);
     const int32_t n_lights = S0.n_lights;
-    const uint32_t cullable_lights = S0.cullable_lights;
     for (int32_t l = 0; l < n_lights; l++) {
-        const bool cullable = l < 32 && ((cullable_lights >> l) & 1u);  // (wave-uniform)
-        const char *rec = light_rec_at(fresh(scene, sc.point.y), l, sc.point.z);
+        const char *rec = light_rec_at(fresh(scene, sc.point.y), l);
         u32x16 lr = load_u32x16(rec);
         pin_scalar(lr);
         v3 light_color = V3(u2f(lr[4]), u2f(lr[5]), u2f(lr[6]));
         v3 Lv = V3(u2f(lr[0]), u2f(lr[1]), u2f(lr[2])) - sc.point;
         float d2 = dot(Lv, Lv);
-        bool traced = hit;  // this lane's shadow ray has to be traced
-        if (cullable) {
+        uint64_t traced_mask;  // the lanes whose shadow ray has to be traced
+        if ((lr[3] & kLightCullable) != 0) {  // (wave-uniform)
             u32x16 lc = load_u32x16(rec + 64);
             pin_scalar(lc);
             v3 La = Lv * shade_rsq(d2);
             // slots are filled in order and an unused one holds cos = 2 (never inside): stop at the first
-            bool in = !(dot(La, V3(u2f(lc[0]), u2f(lc[1]), u2f(lc[2]))) < u2f(lc[3]));
+            uint64_t in = wave_ballot(!(dot(La, V3(u2f(lc[0]), u2f(lc[1]), u2f(lc[2]))) < u2f(lc[3])));
             if (lc[7] != kUnusedCone) {
-                in |= !(dot(La, V3(u2f(lc[4]), u2f(lc[5]), u2f(lc[6]))) < u2f(lc[7]));
+                in |= wave_ballot(!(dot(La, V3(u2f(lc[4]), u2f(lc[5]), u2f(lc[6]))) < u2f(lc[7])));
                 if (lc[11] != kUnusedCone) {
-                    in |= !(dot(La, V3(u2f(lc[8]), u2f(lc[9]), u2f(lc[10]))) < u2f(lc[11]));
-                    if (lc[15] != kUnusedCone) in |= !(dot(La, V3(u2f(lc[12]), u2f(lc[13]), u2f(lc[14]))) < u2f(lc[15]));
+                    in |= wave_ballot(!(dot(La, V3(u2f(lc[8]), u2f(lc[9]), u2f(lc[10]))) < u2f(lc[11])));
+                    if (lc[15] != kUnusedCone) in |= wave_ballot(!(dot(La, V3(u2f(lc[12]), u2f(lc[13]), u2f(lc[14]))) < u2f(lc[15])));
                 }
             }
-            traced = hit & in;
+            traced_mask = hits & in;
+        } else {
+            traced_mask = hits;
         }
-        const uint64_t traced_mask = wave_ballot(traced);
-        if (hit) {
-            wk.rays_shadow++;
-            if (traced) wk.shadow_q++;
-        }
+        wk.rays_shadow += hit ? 1u : 0u;
+        wk.shadow_q += wave_mask_bit(traced_mask) ? 1u : 0u;
         bool lit = hit;
         v3 L;
         float r;
@@ -1615,7 +1639,7 @@ RT_HD void shade_lights(SceneRef scene, bool hit, int accel, ShadeCtx &sc, Stack
             {
                 float len = sqrtf(d2);
                 v3 Le = Lv * (1.0f / len);  // glm::normalize(light - point)
-                if (!traced) Le = V3(NAN, NAN, NAN);
+                if (!wave_mask_bit(traced_mask)) Le = V3(NAN, NAN, NAN);
                 park_shade<F>(stk, sc);
                 Closest cs;
                 // |L| = 1, so the local ray parameter equals the world distance up to rounding: clip there
@@ -1623,7 +1647,7 @@ RT_HD void shade_lights(SceneRef scene, bool hit, int accel, ShadeCtx &sc, Stack
                 unpark_shade<F>(stk, sc);
                 // (everything that follows is formed again from the parked point and the light's record: nothing but
                 // the parked values lives across the query)
-                u32x16 lr2 = load_u32x16(light_rec_at(fresh(scene, sc.point.y), l, sc.point.z));
+                u32x16 lr2 = load_u32x16(light_rec_at(fresh(scene, sc.point.y), l));
                 pin_scalar(lr2);
                 light_color = V3(u2f(lr2[4]), u2f(lr2[5]), u2f(lr2[6]));
                 v3 Lv2 = V3(u2f(lr2[0]), u2f(lr2[1]), u2f(lr2[2])) - sc.point;
@@ -1633,7 +1657,7 @@ RT_HD void shade_lights(SceneRef scene, bool hit, int accel, ShadeCtx &sc, Stack
                 lit = hit & !(mine & (cs.distance < len2));
                 L = Lv2 * (1.0f / len2);
                 r = len2;
-                if (cullable) {  // the lanes whose ray was not traced: the 1-ulp forms, as in a wave that traces nothing
+                if ((lr2[3] & kLightCullable) != 0) {  // the lanes whose ray was not traced: the 1-ulp forms, as in a wave that traces nothing
                     float ri = shade_rsq(d2b);
                     L = select3(mine, L, Lv2 * ri);
                     r = mine ? r : d2b * ri;
@@ -1673,19 +1697,20 @@ template <int F, bool COUNT, class Stack, class Source>
 RT_HD void trace_loop_direct(SceneRef S, int accel, Stack &stk, Work &wk, Source &src) {
     for (;;) {
         v3 o, d;
+        if (!src.more()) break;            // (wave-uniform: the lanes of a wave have the same number of rays)
         const bool live = src.next(o, d);  // (all lanes call next() alike, in step; a source may hand a lane no ray while others get one)
-        if (wave_ballot(live) == 0) break;
         Closest c;
         find_closest<F, COUNT>(S, o, d, accel, -1, INFINITY, -INFINITY, c, stk, wk);
-        if (live) wk.rays_primary++;
-        bool hit = live & (c.object >= 0);
+        wk.rays_primary += live ? 1u : 0u;
         rt_hit_record *fh = src.first_hit();
         if (fh && live) hit_record<F, COUNT>(S, c, o, d, *fh, wk);
+        c.object = live ? c.object : -1;   // (a lane without a ray has no hit: from here on "hit" is one comparison)
+        const uint64_t hits = wave_ballot(c.object >= 0);
         ShadeCtx sc;
-        surface_shade<F, COUNT>(S, c, hit, o, d, sc, stk, wk);
-        shade_lights<F, COUNT>(S, hit, accel, sc, stk, wk);
+        surface_shade<F, COUNT>(S, c, hits, o, d, sc, stk, wk);
+        shade_lights<F, COUNT>(S, hits, accel, sc, stk, wk);
         v3 radiance = V3(0, 0, 0);
-        if (hit) radiance = radiance + shade_end(sc) * 1.0f;
+        if (wave_mask_bit(hits)) radiance = radiance + shade_end(sc) * 1.0f;
         if (live) src.done(radiance);
     }
 }
@@ -1716,8 +1741,9 @@ RT_HD void trace_loop(SceneRef S, int max_depth, int accel, Stack &stk, Work &wk
         }
         primary = false;
         ShadeCtx sc;
-        surface_shade<F, COUNT>(S, c, hit, o, d, sc, stk, wk);
-        shade_lights<F, COUNT>(S, hit, accel, sc, stk, wk);
+        const uint64_t hits = wave_ballot(c.object >= 0);
+        surface_shade<F, COUNT>(S, c, hits, o, d, sc, stk, wk);
+        shade_lights<F, COUNT>(S, hits, accel, sc, stk, wk);
         if (hit) {
             v3 local = shade_end(sc);
             float refl = sc.refl, refr = sc.refr;
@@ -1764,6 +1790,7 @@ struct OneRay {
     v3 o, d, radiance;
     rt_hit_record *hit;
     bool taken;
+    RT_HD bool more() const { return !taken; }
     RT_HD bool next(v3 &ro, v3 &rd) { if (taken) return false; taken = true; ro = o; rd = d; return true; }
     RT_HD void done(v3 r) { radiance = r; }
     RT_HD rt_hit_record *first_hit() { return hit; }
@@ -1866,6 +1893,7 @@ struct PixelTaps {
         if (PARKED) { stk->cold_put(kColdTapDx, dx0); stk->cold_put(kColdTapDy, dy0); cold_put3(*stk, kColdTapColor, V3(0, 0, 0)); }
         else { dx = dx0; dy = dy0; color = V3(0, 0, 0); }
     }
+    RT_HD bool more() const { return k < taps; }
     RT_HD bool next(v3 &ro, v3 &rd) {
         if (k >= taps) return false;
         ro = V3(0, 0, 0);

@@ -80,7 +80,7 @@ struct WaveStack {
     __shared__ uint32_t name##_lds[kWavesPerBlock * kStackWords];        \
     __shared__ float name##_cold[(cold_slots(features) + (extra)) * kBlock]; \
     WaveStack name;                                                      \
-    name.base = name##_lds + (threadIdx.x >> 6) * kStackWords;           \
+    name.base = name##_lds + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * kStackWords; /* (one address per wave: scalar arithmetic) */ \
     name.cold = name##_cold + threadIdx.x
 
 __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
@@ -465,6 +465,7 @@ struct TapSlice {  // a trace_loop source: taps [k, k_end) of one pixel; the pix
     float *slots;  // this lane's column of the LDS array [kRoundTaps][3][pixels of the block]; nullptr: sum into `color` at once
     int stride;    // pixels of the block
     v3 color;      // the pixel's running sum when the lane traces all its taps itself (slots == nullptr)
+    __device__ bool more() const { return k < k_end; }
     __device__ bool next(v3 &ro, v3 &rd) {
         if (k >= k_end) return false;
         ro = V3(0, 0, 0);
@@ -964,6 +965,16 @@ static int dev_alloc(rt_ctx *ctx, T **out, size_t count, const void *src, bool s
     return RT_OK;
 }
 
+// ctx->S and, behind it, the records of the lights beyond its own table (queued on the context's stream; `lights` must
+// outlive the copy: the callers synchronise)
+static int upload_scene_record(rt_ctx *ctx, const std::vector<LightRec> &lights) {
+    RT_HIP(hipMemcpyAsync(ctx->d_scene, &ctx->S, sizeof ctx->S, hipMemcpyHostToDevice, ctx->stream));
+    if ((int)lights.size() > kEmbLights)
+        RT_HIP(hipMemcpyAsync(reinterpret_cast<char *>(ctx->d_scene) + sizeof(DevScene), lights.data() + kEmbLights,
+                              (lights.size() - kEmbLights) * sizeof(LightRec), hipMemcpyHostToDevice, ctx->stream));
+    return RT_OK;
+}
+
 static void free_scene(rt_ctx *ctx) {
     for (void *p : ctx->allocs) (void)hipFree(p);
     ctx->allocs.clear();
@@ -1150,9 +1161,7 @@ extern "C" int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *sc) {
     std::vector<LightCull> cull;
     uint32_t cullable = make_light_cull(sc, ctx->meshes, planes_skip_lights, cull);
     std::vector<LightRec> light_recs;
-    make_light_recs(sc, cull, light_recs);
-    LightRec *d_light_recs;
-    if ((rc = dev_alloc(ctx, &d_light_recs, light_recs.size(), light_recs.data()))) return rc;
+    make_light_recs(sc, cull, cullable, light_recs);
     if ((rc = dev_alloc(ctx, &ctx->d_nodes, (size_t)node_total, (const void *)nullptr))) return rc;
     if ((rc = dev_alloc(ctx, &ctx->d_meshes, ctx->meshes.size(), ctx->meshes.data()))) return rc;
 
@@ -1176,9 +1185,14 @@ extern "C" int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *sc) {
     S.objects = d_objects; S.spheres = d_spheres; S.planes = d_planes; S.cones = d_cones; S.meshes = ctx->d_meshes;
     S.tri_test = ctx->d_tri_test; S.tri_key = ctx->d_tri_key; S.tri_orig = ctx->d_tri_orig;
     S.tri_nrm = d_nrm; S.tri_uv = d_uv; S.tri_material = d_tmat; S.tri_frag = ctx->d_tri_frag; S.tri_sub = ctx->d_tri_sub;
-    S.gate_tri = d_gate; S.light_recs = d_light_recs; S.cullable_lights = cullable; S.gate_entry_first = (scene_features(sc) & F_SECONDARY) ? 1 : 0; S.nodes = ctx->d_nodes; S.materials = d_materials; S.textures = d_tex; S.srgb_lut = d_lut;
+    S.gate_tri = d_gate; S.unused_lights = nullptr; S.cullable_lights = cullable; S.gate_entry_first = (scene_features(sc) & F_SECONDARY) ? 1 : 0; S.nodes = ctx->d_nodes; S.materials = d_materials; S.textures = d_tex; S.srgb_lut = d_lut;
     fill_embedded(S, axis_pairs, gen_planes, ctx->meshes, obj_recs, light_recs);
-    if ((rc = dev_alloc(ctx, &ctx->d_scene, 1, &S))) return rc;
+    {   // the scene record, then the records of the lights that do not fit its own table (light_rec_at)
+        char *mem;
+        if ((rc = dev_alloc(ctx, &mem, scene_record_bytes(sc->n_lights), (const void *)nullptr))) return rc;
+        ctx->d_scene = reinterpret_cast<DevScene *>(mem);
+        if ((rc = upload_scene_record(ctx, light_recs))) return rc;
+    }
     RT_HIP(hipStreamSynchronize(ctx->stream));  // the caller's arrays may go away after return
     ctx->features = scene_features(sc);
     ctx->uploaded = true;
@@ -1266,13 +1280,12 @@ extern "C" int rt_scene_update(rt_ctx *ctx, const rt_scene_desc *sc) {
     std::vector<LightCull> cull;
     S.cullable_lights = make_light_cull(sc, ctx->meshes, S.planes_skip_lights, cull);
     std::vector<LightRec> light_recs;
-    make_light_recs(sc, cull, light_recs);
-    if ((rc = dev_update(ctx, S.light_recs, light_recs.data(), light_recs.size()))) return rc;
+    make_light_recs(sc, cull, S.cullable_lights, light_recs);
     if ((rc = dev_update(ctx, S.meshes, ctx->meshes.data(), ctx->meshes.size()))) return rc;
     fill_embedded(S, axis_pairs, gen_planes, ctx->meshes, obj_recs, light_recs);
     ctx->features = scene_features(sc);
     S.gate_entry_first = (ctx->features & F_SECONDARY) ? 1 : 0;
-    RT_HIP(hipMemcpyAsync(ctx->d_scene, &S, sizeof S, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = upload_scene_record(ctx, light_recs))) return rc;  // (the number of lights is the uploaded scene's)
     RT_HIP(hipStreamSynchronize(ctx->stream));  // the caller's arrays may go away after return
     return RT_OK;
 }

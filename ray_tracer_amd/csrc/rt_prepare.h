@@ -505,11 +505,13 @@ inline void make_obj_recs(const rt_scene_desc *sc, const std::vector<MatRec> &ma
 }
 
 // The per-light records: position, colour and the cones of make_light_cull.
-inline void make_light_recs(const rt_scene_desc *sc, const std::vector<LightCull> &cull, std::vector<LightRec> &out) {
+// cullable: bit l set when the cones of light l decide alone whether a shadow query is needed (make_light_cull)
+inline void make_light_recs(const rt_scene_desc *sc, const std::vector<LightCull> &cull, uint32_t cullable, std::vector<LightRec> &out) {
     out.assign(std::max(sc->n_lights, 1), LightRec{});
     for (int l = 0; l < sc->n_lights; l++) {
         LightRec &r = out[l];
         for (int a = 0; a < 3; a++) { r.pos[a] = sc->light_pos[3 * l + a]; r.color[a] = sc->light_color[3 * l + a]; }
+        r.flags = (l < 32 && ((cullable >> l) & 1u)) ? kLightCullable : 0u;
         r.cull = cull[l];
     }
 }

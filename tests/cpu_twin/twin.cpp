@@ -29,9 +29,12 @@ struct VecStack {  // the host build's "wave" is one lane
     void get(int slot, int32_t &n, uint64_t &m) { n = node[slot]; m = mask[slot]; }
 };
 
+constexpr int kTwinMaxLights = 64;  // (test scenes have a handful)
 struct Twin {
     std::string err;
-    DevScene S{};
+    // the scene record with the records of the lights beyond its own table right behind it (light_rec_at)
+    struct alignas(64) Record { DevScene S{}; LightRec more_lights[kTwinMaxLights - kEmbLights]; } rec;
+    DevScene &S = rec.S;
     std::vector<rt_object> objects;
     std::vector<rt_sphere> spheres;
     std::vector<rt_plane> planes;
@@ -142,7 +145,12 @@ void *twin_create(const rt_scene_desc *sc, char *errbuf, int errcap) {
         if (errbuf && errcap > 0) { std::strncpy(errbuf, bad.c_str(), errcap - 1); errbuf[errcap - 1] = 0; }
         return nullptr;
     }
+    if (sc->n_lights > kTwinMaxLights) {
+        if (errbuf && errcap > 0) { std::strncpy(errbuf, "the twin holds at most 64 lights", errcap - 1); errbuf[errcap - 1] = 0; }
+        return nullptr;
+    }
     Twin *t = new Twin();
+    static_assert(offsetof(Twin::Record, more_lights) == sizeof(DevScene), "the lights beyond the scene record's table follow it directly");
     t->objects.assign(sc->objects, sc->objects + sc->n_objects);
     t->spheres.assign(sc->spheres, sc->spheres + sc->n_spheres);
     t->planes.assign(sc->planes, sc->planes + sc->n_planes);
@@ -202,8 +210,9 @@ void *twin_create(const rt_scene_desc *sc, char *errbuf, int errcap) {
     S.tri_nrm = t->tri_nrm.data(); S.tri_uv = t->tri_uv.data(); S.tri_material = t->tri_material.data();
     S.tri_frag = t->tri_frag.data(); S.tri_sub = t->tri_sub.data(); S.gate_tri = t->gate.data(); S.nodes = t->nodes.data();
     S.cullable_lights = make_light_cull(sc, t->meshes, S.planes_skip_lights, t->light_cull);
-    make_light_recs(sc, t->light_cull, t->light_recs);
-    S.light_recs = t->light_recs.data();
+    make_light_recs(sc, t->light_cull, S.cullable_lights, t->light_recs);
+    S.unused_lights = nullptr;
+    for (int l = kEmbLights; l < sc->n_lights; l++) t->rec.more_lights[l - kEmbLights] = t->light_recs[l];
     S.srgb_lut = t->srgb_lut.data(); S.gate_entry_first = (scene_features(sc) & F_SECONDARY) ? 1 : 0;
     S.materials = t->materials.data(); S.textures = t->textures.data();
     fill_embedded(S, t->axis_pairs, t->gen_planes, t->meshes, t->obj_recs, t->light_recs);

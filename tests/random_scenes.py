@@ -161,6 +161,25 @@ def build(seed):
     return sp, f"seed {seed}: " + ", ".join(what)
 
 
+def many_lights(n_lights, with_sphere):
+    """A room of axis planes with a smooth closed mesh (and, with_sphere, a sphere, which keeps every shadow query)
+    under n_lights lights: more than a scene record's own light table holds."""
+    rng = np.random.default_rng(77 + n_lights + (1 if with_sphere else 0))
+    sp = ScenePair()
+    grey = _material(rng, "diffuse"); shiny = _material(rng, "shiny")
+    sp.plane((0, -3, 0), (0, 1, 0), grey); sp.plane((0, 0, 24), (0, 0, -1), grey); sp.plane((-12, 0, 0), (1, 0, 0), shiny)
+    sp.plane((12, 0, 0), (-1, 0, 0), grey); sp.plane((0, 18, 0), (0, -1, 0), grey)
+    pos, nrm = _shell(rng, 10, 14)
+    M = rt.matmul(rt.translate((0.5, 0.5, 11.0)), rt.scale((2.5, 2.0, 2.5)))
+    sp.mesh(pos, nrm, M, shiny, False)
+    if with_sphere:
+        sp.sphere(rt.translate((-4.0, -1.0, 9.0)), _material(rng, "diffuse"))
+    for k in range(n_lights):
+        a = 2 * np.pi * k / n_lights
+        sp.light((7 * np.cos(a), 9 + 4 * np.sin(3 * a), 9 + 7 * np.sin(a)), rng.uniform(0.05, 0.25, 3))
+    return sp, f"{n_lights} lights" + (", sphere" if with_sphere else "")
+
+
 def rays(sp, seed, w=72, h=54, n_random=1200):
     """Camera rays of a small frame, rays aimed at mesh vertices and edge midpoints, and random rays from random origins."""
     import parity

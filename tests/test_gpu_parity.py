@@ -473,6 +473,27 @@ def test_random_scene_equals_oracle_on_gpu(seed):
     parity.check_rgb8(ref_rgb8, rgb8, what)
 
 
+@pytest.mark.parametrize("n_lights,with_sphere", [(11, False), (9, True)])
+def test_more_lights_than_the_scene_record_holds_on_gpu(n_lights, with_sphere):
+    """Lights beyond the scene record's own table live right behind the record in device memory: a frame under 9 and
+    11 lights (with and without the wave-wide skipping of shadow queries) against the oracle's, then again after
+    rt_scene_update with the lights moved."""
+    import random_scenes
+    sp, what = random_scenes.many_lights(n_lights, with_sphere)
+    ref_rgb, ref_rgb8, _ = sp.orc.render(96, 64, mode=rt.MODE_GRID, grid_m=2, max_depth=4)
+    ctx = rt.Context(0)
+    try:
+        ctx.upload(sp.host)
+        rgb, rgb8 = ctx.render(96, 64, mode=rt.MODE_GRID, grid_m=2, max_depth=4)
+        ctx.update(sp.host)
+        again, again8 = ctx.render(96, 64, mode=rt.MODE_GRID, grid_m=2, max_depth=4)
+    finally:
+        ctx.close()
+    parity.check_radiance(ref_rgb, rgb, what)
+    parity.check_rgb8(ref_rgb8, rgb8, what)
+    assert np.array_equal(rgb, again, equal_nan=True) and np.array_equal(rgb8, again8)
+
+
 @pytest.mark.parametrize("seed", range(3))
 def test_sphere_ball_test_drops_no_hit_on_gpu(seed):
     """Spheres under hard transformations (axis ratios up to 60:1, tiny and far, far from the world's origin)

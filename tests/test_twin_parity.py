@@ -145,6 +145,19 @@ def test_random_scene_equals_oracle(seed):
     assert (ref["hit"] == 1).mean() > 0.5
 
 
+@pytest.mark.parametrize("n_lights,with_sphere", [(11, False), (9, True)])
+def test_more_lights_than_the_scene_record_holds(n_lights, with_sphere):
+    """Lights beyond the scene record's own table live right behind the record: a frame under 9 and 11 lights (with
+    and without the wave-wide skipping of shadow queries) against the oracle's."""
+    sp, what = random_scenes.many_lights(n_lights, with_sphere)
+    ref_rgb, ref_rgb8, _ = sp.orc.render(64, 48, mode=rt.MODE_GRID, grid_m=2, max_depth=4)
+    tw = T.Twin(sp.host)
+    rgb, rgb8, _ = tw.render(64, 48, mode=rt.MODE_GRID, grid_m=2, max_depth=4)
+    parity.check_radiance(ref_rgb, rgb, what)
+    parity.check_rgb8(ref_rgb8, rgb8, what)
+    assert (np.asarray(ref_rgb).reshape(-1, 3).sum(axis=1) > 0).mean() > 0.9
+
+
 @pytest.mark.parametrize("seed", range(3))
 def test_sphere_ball_test_drops_no_hit(seed):
     """Spheres and cones under hard transformations, rays that graze them: the ball tests in front of the exact
