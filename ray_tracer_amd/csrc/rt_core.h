@@ -383,7 +383,7 @@ struct alignas(64) DevScene {
     const f4 *tri_test;        // 3 x f4 per sorted triangle: p1 p2 p3 sn
     const uint32_t *tri_key;   // per sorted triangle: 2*frag + (1 - sub), the tie-break order
     const f4 *gate_tri;        // 3 x f4 per Box triangle, 12 per mesh
-    int32_t gate_entry_first;  // the scene has secondary rays: its kernels test the Box gate's entry face first (mesh_geom); read by the counting kernel only
+    int32_t unused_gate_order;  // (keeps the layout)
     int32_t pad0;
     // ---- from a closest hit to a shading context
     const ObjRec *obj_recs;       // per object (the first kEmbObjects also in obj_first)
@@ -943,7 +943,7 @@ struct MeshHit {
 // only sees back faces, so the gate is closed; (3) for the remaining rays the tree is searched
 // first and the 12 exact triangle tests run only for rays that found a triangle (the gate is a
 // conjunct of the result, so the order does not matter).
-template <bool COUNT, bool ENTRY_FIRST, class Stack>
+template <bool COUNT, class Stack>
 RT_HD bool mesh_geom(SceneRef S, const MeshHead &h, const DevMesh &m, v3 ro, v3 rd, v3 winv, v3 woi, uint64_t want, int accel, float clip, MeshHit &mh, Stack &stk, Work &wk) {
     // want: the lanes whose rays take part, a wave-uniform mask (every test below is one comparison whose lane mask is
     // combined with it by scalar instructions)
@@ -992,15 +992,12 @@ RT_HD bool mesh_geom(SceneRef S, const MeshHead &h, const DevMesh &m, v3 ro, v3 
         const v3 bd = xform_dir(to_box, rd2), bo = xform_point(to_box, ro2);
         const f4 *gt = S.gate_tri + 3 * (size_t)h.gate_tri_offset;
         bool any = false;
-        // The gate is the OR of the 12 one-sided triangle tests, so their order is free.  ENTRY_FIRST (the kernels for scenes
-        // with secondary rays, whose rays reach a box from every side): the two triangles of the face the ray enters through
-        // (largest entry parameter of the three slabs) come first and nearly always answer; the others run only for lanes
-        // they left undecided.  Faces in make_gate_tris' order: z lo, x hi, z hi, x lo, y hi, y lo.  Camera and light rays
-        // of a scene without secondary rays find their face early in the fixed order, and there the extra registers cost more
-        // than the tests saved (teapot frame 2 % slower, shells frame 3.5 % faster).
-        int32_t face = -1;
-        const bool entry_first = COUNT ? S.gate_entry_first != 0 : ENTRY_FIRST;  // the counting kernel serves every scene: it does what the scene's own kernel does
-        if (entry_first) {
+        // The gate is the OR of the 12 one-sided triangle tests, so their order is free: the two triangles of the face the
+        // ray enters through (largest entry parameter of the three slabs) come first and nearly always answer; the others
+        // run only for lanes they left undecided (teapot frame: 24 M instead of 55 M executed gate triangle tests, shells
+        // 340 M instead of 1595 M).  Faces in make_gate_tris' order: z lo, x hi, z hi, x lo, y hi, y lo.
+        int32_t face;
+        {
             float ex = ((bd.x > 0 ? m.gate_lo[0] : m.gate_hi[0]) - bo.x) * safe_rcp(bd.x);
             float ey = ((bd.y > 0 ? m.gate_lo[1] : m.gate_hi[1]) - bo.y) * safe_rcp(bd.y);
             float ez = ((bd.z > 0 ? m.gate_lo[2] : m.gate_hi[2]) - bo.z) * safe_rcp(bd.z);
@@ -1010,7 +1007,7 @@ RT_HD bool mesh_geom(SceneRef S, const MeshHead &h, const DevMesh &m, v3 ro, v3 
         }
         for (int i = 0; i < 12; i++) {
             if (any) break;
-            if (entry_first && (i >> 1) == face) continue;
+            if ((i >> 1) == face) continue;
             if (COUNT) wk.gate_tri++;
             any = tri_hits(gt, i, bo, bd);
         }
@@ -1103,6 +1100,7 @@ struct PlaneCand {
     int32_t object;
 };
 constexpr float kEstMin = kMinDist * (1.0f - 1e-5f);
+RT_HD uint32_t umin32(uint32_t a, uint32_t b) { return a < b ? a : b; }
 RT_HD float med3(float a, float b, float c) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return __builtin_amdgcn_fmed3f(a, b, c);
@@ -1138,7 +1136,9 @@ RT_HD float pair_coord(uint32_t coord, uint32_t cs, uint32_t light_bit) { return
 template <bool COUNT>
 RT_HD void plane_general(const u32x16 &g, int at, uint32_t light_bit, v3 ro, v3 rd, PlaneCand &c, Work &wk) {
     int32_t idx = (int32_t)g[at + 6];
-    if (idx < 0 || (g[at + 7] & light_bit) != 0) return;  // padding, or cannot shadow this wave's light (wave-uniform)
+    // padding, or cannot shadow this wave's light (wave-uniform; formed as one integer: a condition built from two stays
+    // a pair of lane masks)
+    if ((((uint32_t)idx >> 31) | (g[at + 7] & light_bit)) != 0) return;
     if (COUNT) wk.plane++;
     v3 n = V3(u2f(g[at]), u2f(g[at + 1]), u2f(g[at + 2]));
     float DdotN = dot(rd, n);
@@ -1169,7 +1169,8 @@ RT_HD void planes_pass(SceneRef S, const u32x16 &g0, const u32x16 &g1, int32_t n
     {
         // (a shadow ray's wave skips a pair neither of whose planes can shadow its light: wave-uniform; for other rays
         // light_bit is a constant 0 and the checks fold away)
-#define RT_PAIR_LIVE(g, at) (light_bit == 0 || ((int32_t)g[at + 1] >= 0 && (g[at + 2] & light_bit) == 0) || ((int32_t)g[at + 4] >= 0 && (g[at + 5] & light_bit) == 0))
+        // (a pair is dead when neither of its planes is there and can shadow the wave's light: one integer per plane, 0 = alive)
+#define RT_PAIR_LIVE(g, at) (umin32((g[at + 1] >> 31) | (g[at + 2] & light_bit), (g[at + 4] >> 31) | (g[at + 5] & light_bit)) == 0)
         if (RT_PAIR_LIVE(g0, 0))
             plane_axis_pair<COUNT>(pair_coord(g0[0], g0[2], light_bit), (int32_t)g0[1], pair_coord(g0[3], g0[5], light_bit), (int32_t)g0[4], ro.x, rd.x, rinv.x, c, wk);
         if (RT_PAIR_LIVE(g0, 8))
@@ -1221,7 +1222,7 @@ RT_HD void find_closest(SceneRef scene, v3 ro, v3 rd, int accel, int light, floa
     SceneRef S = fresh(scene, rd.x);
     // light: >= 0 when the wave's rays are shadow rays towards that light (wave-uniform: the light loop keeps the lanes
     // of a wave in step); planes that cannot shadow it are skipped.
-    const uint32_t light_bit = (light >= 0 && light < 32) ? 1u << light : 0u;
+    const uint32_t light_bit = (uint32_t)light < 32u ? 1u << (light & 31) : 0u;
     best.distance = INFINITY;
     best.object = -1;
     best.t = 0;
@@ -1266,10 +1267,10 @@ RT_HD void find_closest(SceneRef scene, v3 ro, v3 rd, int accel, int light, floa
     const uint64_t valid = ~(wave_ballot(__builtin_isunordered(ro.x, ro.y)) | wave_ballot(__builtin_isunordered(ro.z, rd.x)) |
                              wave_ballot(__builtin_isunordered(rd.y, rd.z)));
     u32x16 next_head = head0;  // the first mesh's, from the batch of loads above; a later one is fetched when the mesh before it is done
+    // reciprocals for the world-box tests: the first mesh takes the plane pass's, a later mesh forms them again (they are
+    // not held through the traversal of the mesh before)
+    v3 winv = V3(safe_rcp_of(rd.x, rinv.x), safe_rcp_of(rd.y, rinv.y), safe_rcp_of(rd.z, rinv.z));
     for (int32_t i = 0; i < n_meshes; i++) {
-        // (the reciprocals per mesh, not held through the traversal of the mesh before)
-        const v3 rdi = again(rd, best.distance);
-        const v3 winv = V3(safe_rcp(rdi.x), safe_rcp(rdi.y), safe_rcp(rdi.z));
         const v3 woi = ro * winv;
         union { u32x16 raw; MeshHead h; } head;
         pin_scalar(next_head);
@@ -1278,11 +1279,15 @@ RT_HD void find_closest(SceneRef scene, v3 ro, v3 rd, int accel, int light, floa
         if (idx >= 0) {  // (wave-uniform) in the object list
             MeshHit mh;
             const uint64_t want = valid & ~wave_ballot(best.distance < occl);
-            if (mesh_geom<COUNT, (F & F_SECONDARY) != 0>(S, head.h, S.meshes[i], ro, rd, winv, woi, want, accel, clip, mh, stk, wk) && mh.from_outside && closer(mh.distance, idx, best)) {
+            if (mesh_geom<COUNT>(S, head.h, S.meshes[i], ro, rd, winv, woi, want, accel, clip, mh, stk, wk) && mh.from_outside && closer(mh.distance, idx, best)) {
                 best.distance = mh.distance; best.object = idx; best.t = mh.t; best.k = mh.k;
             }
         }
-        if (i + 1 < n_meshes) next_head = load_u32x16(mesh_head_at(S, i + 1, best.distance));
+        if (i + 1 < n_meshes) {
+            next_head = load_u32x16(mesh_head_at(S, i + 1, best.distance));
+            const v3 rdi = again(rd, best.distance);
+            winv = V3(safe_rcp(rdi.x), safe_rcp(rdi.y), safe_rcp(rdi.z));
+        }
     }
     }
 }
@@ -1369,7 +1374,7 @@ RT_HD void intersect_object(SceneRef S, int32_t k, v3 ro, v3 rd, int accel, rt_h
     } else if (ob.kind == RT_OBJ_MESH) {
         MeshHit mh;
         v3 winv = V3(safe_rcp(rd.x), safe_rcp(rd.y), safe_rcp(rd.z));
-        hit = mesh_geom<COUNT, false>(S, S.meshes[ob.index], S.meshes[ob.index], ro, rd, winv, ro * winv, ~0ull, accel, INFINITY, mh, stk, wk);
+        hit = mesh_geom<COUNT>(S, S.meshes[ob.index], S.meshes[ob.index], ro, rd, winv, ro * winv, ~0ull, accel, INFINITY, mh, stk, wk);
         if (hit) { c.t = mh.t; c.k = mh.k; c.distance = mh.distance; from_outside = mh.from_outside; }
     } else {
         QuadricHit q;
@@ -1607,16 +1612,16 @@ RT_HD void shade_lights(SceneRef scene, uint64_t hits, int accel, ShadeCtx &sc, 
     const int32_t n_lights = S0.n_lights;
     for (int32_t l = 0; l < n_lights; l++) {
         const char *rec = light_rec_at(fresh(scene, sc.point.y), l);
-        u32x16 lr = load_u32x16(rec);
+        u32x16 lr = load_u32x16(rec), lc = load_u32x16(rec + 64);  // (both halves in one batch: the second is only looked at for a cullable light)
         pin_scalar(lr);
         v3 light_color = V3(u2f(lr[4]), u2f(lr[5]), u2f(lr[6]));
         v3 Lv = V3(u2f(lr[0]), u2f(lr[1]), u2f(lr[2])) - sc.point;
         float d2 = dot(Lv, Lv);
+        const float ri_approx = shade_rsq(d2);
+        const v3 La = Lv * ri_approx;  // the 1-ulp direction: for the cone tests, and for the shading of lanes whose ray is not traced
         uint64_t traced_mask;  // the lanes whose shadow ray has to be traced
         if ((lr[3] & kLightCullable) != 0) {  // (wave-uniform)
-            u32x16 lc = load_u32x16(rec + 64);
             pin_scalar(lc);
-            v3 La = Lv * shade_rsq(d2);
             // slots are filled in order and an unused one holds cos = 2 (never inside): stop at the first
             uint64_t in = wave_ballot(!(dot(La, V3(u2f(lc[0]), u2f(lc[1]), u2f(lc[2]))) < u2f(lc[3])));
             if (lc[7] != kUnusedCone) {
@@ -1637,8 +1642,8 @@ RT_HD void shade_lights(SceneRef scene, uint64_t hits, int accel, ShadeCtx &sc, 
         float r;
         if (traced_mask != 0) {  // (wave-uniform)
             {
-                float len = sqrtf(d2);
-                v3 Le = Lv * (1.0f / len);  // glm::normalize(light - point)
+                const float len = sqrtf(d2), inv_len = 1.0f / len;
+                v3 Le = Lv * inv_len;  // glm::normalize(light - point)
                 if (!wave_mask_bit(traced_mask)) Le = V3(NAN, NAN, NAN);
                 park_shade<F>(stk, sc);
                 Closest cs;
@@ -1651,22 +1656,21 @@ RT_HD void shade_lights(SceneRef scene, uint64_t hits, int accel, ShadeCtx &sc, 
                 pin_scalar(lr2);
                 light_color = V3(u2f(lr2[4]), u2f(lr2[5]), u2f(lr2[6]));
                 v3 Lv2 = V3(u2f(lr2[0]), u2f(lr2[1]), u2f(lr2[2])) - sc.point;
-                float d2b = dot(Lv2, Lv2);
-                float len2 = sqrtf(d2b);
+                const float len2 = len;  // (the length and its reciprocal are the two values held through the query)
                 const bool mine = wave_mask_bit(traced_mask);
                 lit = hit & !(mine & (cs.distance < len2));
-                L = Lv2 * (1.0f / len2);
+                L = Lv2 * inv_len;
                 r = len2;
                 if ((lr2[3] & kLightCullable) != 0) {  // the lanes whose ray was not traced: the 1-ulp forms, as in a wave that traces nothing
+                    float d2b = dot(Lv2, Lv2);
                     float ri = shade_rsq(d2b);
                     L = select3(mine, L, Lv2 * ri);
                     r = mine ? r : d2b * ri;
                 }
             }
         } else {
-            float ri = shade_rsq(d2);
-            L = Lv * ri;
-            r = d2 * ri;
+            L = La;
+            r = d2 * ri_approx;
         }
         if (lit) shade_light<COUNT>(sc, light_color, L, r, wk);
     }

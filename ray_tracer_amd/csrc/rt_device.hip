@@ -1185,7 +1185,7 @@ extern "C" int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *sc) {
     S.objects = d_objects; S.spheres = d_spheres; S.planes = d_planes; S.cones = d_cones; S.meshes = ctx->d_meshes;
     S.tri_test = ctx->d_tri_test; S.tri_key = ctx->d_tri_key; S.tri_orig = ctx->d_tri_orig;
     S.tri_nrm = d_nrm; S.tri_uv = d_uv; S.tri_material = d_tmat; S.tri_frag = ctx->d_tri_frag; S.tri_sub = ctx->d_tri_sub;
-    S.gate_tri = d_gate; S.unused_lights = nullptr; S.cullable_lights = cullable; S.gate_entry_first = (scene_features(sc) & F_SECONDARY) ? 1 : 0; S.nodes = ctx->d_nodes; S.materials = d_materials; S.textures = d_tex; S.srgb_lut = d_lut;
+    S.gate_tri = d_gate; S.unused_lights = nullptr; S.cullable_lights = cullable; S.unused_gate_order = 0; S.nodes = ctx->d_nodes; S.materials = d_materials; S.textures = d_tex; S.srgb_lut = d_lut;
     fill_embedded(S, axis_pairs, gen_planes, ctx->meshes, obj_recs, light_recs);
     {   // the scene record, then the records of the lights that do not fit its own table (light_rec_at)
         char *mem;
@@ -1284,7 +1284,7 @@ extern "C" int rt_scene_update(rt_ctx *ctx, const rt_scene_desc *sc) {
     if ((rc = dev_update(ctx, S.meshes, ctx->meshes.data(), ctx->meshes.size()))) return rc;
     fill_embedded(S, axis_pairs, gen_planes, ctx->meshes, obj_recs, light_recs);
     ctx->features = scene_features(sc);
-    S.gate_entry_first = (ctx->features & F_SECONDARY) ? 1 : 0;
+    S.unused_gate_order = 0;
     if ((rc = upload_scene_record(ctx, light_recs))) return rc;  // (the number of lights is the uploaded scene's)
     RT_HIP(hipStreamSynchronize(ctx->stream));  // the caller's arrays may go away after return
     return RT_OK;

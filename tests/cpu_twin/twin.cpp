@@ -213,7 +213,7 @@ void *twin_create(const rt_scene_desc *sc, char *errbuf, int errcap) {
     make_light_recs(sc, t->light_cull, S.cullable_lights, t->light_recs);
     S.unused_lights = nullptr;
     for (int l = kEmbLights; l < sc->n_lights; l++) t->rec.more_lights[l - kEmbLights] = t->light_recs[l];
-    S.srgb_lut = t->srgb_lut.data(); S.gate_entry_first = (scene_features(sc) & F_SECONDARY) ? 1 : 0;
+    S.srgb_lut = t->srgb_lut.data(); S.unused_gate_order = 0;
     S.materials = t->materials.data(); S.textures = t->textures.data();
     fill_embedded(S, t->axis_pairs, t->gen_planes, t->meshes, t->obj_recs, t->light_recs);
     return t;
