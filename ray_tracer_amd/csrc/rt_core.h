@@ -867,8 +867,8 @@ RT_HD void bvh_walk(const BvhNode *nodes, const f4 *tt, const uint32_t *keys, in
                 bool h1 = slab_fused(u2f(nd[6]), u2f(nd[7]), u2f(nd[8]), u2f(nd[9]), u2f(nd[10]), u2f(nd[11]), inv, oi, tm, n1);
                 b0 = wave_ballot(h0); b1 = wave_ballot(h1);
             }
-            // (the second child's mask is tested at two places; through an alias the second test is a scalar compare of
-            // its own: a condition shared between blocks is kept as a lane mask and inverted by two vector instructions)
+            // (A wave-uniform condition that is looked at in two blocks is kept as a lane mask and inverted by two vector
+            // instructions; a mask that is tested twice therefore goes through uniform_alias64 the second time.)
             if (b0 != 0) {
                 if (b1 != 0) stk.put(sp++, (int32_t)nd[13], b1);
                 cur = (int32_t)nd[12]; inm = b0;
@@ -1170,7 +1170,9 @@ RT_HD void planes_pass(SceneRef S, const u32x16 &g0, const u32x16 &g1, int32_t n
         // (a shadow ray's wave skips a pair neither of whose planes can shadow its light: wave-uniform; for other rays
         // light_bit is a constant 0 and the checks fold away)
         // (a pair is dead when neither of its planes is there and can shadow the wave's light: one integer per plane, 0 = alive)
-#define RT_PAIR_LIVE(g, at) (umin32((g[at + 1] >> 31) | (g[at + 2] & light_bit), (g[at + 4] >> 31) | (g[at + 5] & light_bit)) == 0)
+        // (for rays that are no shadow rays light_bit is the constant 0 once find_closest is inlined, and every pair is evaluated
+        // without a look: an empty pair holds NaN coordinates and yields no candidate)
+#define RT_PAIR_LIVE(g, at) (__builtin_constant_p(light_bit) || umin32((g[at + 1] >> 31) | (g[at + 2] & light_bit), (g[at + 4] >> 31) | (g[at + 5] & light_bit)) == 0)
         if (RT_PAIR_LIVE(g0, 0))
             plane_axis_pair<COUNT>(pair_coord(g0[0], g0[2], light_bit), (int32_t)g0[1], pair_coord(g0[3], g0[5], light_bit), (int32_t)g0[4], ro.x, rd.x, rinv.x, c, wk);
         if (RT_PAIR_LIVE(g0, 8))

@@ -426,7 +426,10 @@ __device__ __forceinline__ void fill_grid_table(float *s_grid_off, const RenderA
 
 template <int F, bool COUNT>
 __global__ __launch_bounds__(kBlock, render_waves(F, COUNT)) void k_render(const DevScene *scene, RenderArgs a, float *rgb_tiles, uint8_t *rgb8_tiles,
-                                                   unsigned long long *counters) {
+                                                   unsigned long long *counters, uint32_t *tile_times) {
+    // tile_times (may be null): the block leaves its tile's time there (100 MHz ticks), for the kernels that choose per
+    // tile by the time a tile took in the frame before
+    const unsigned long long t0 = tile_times ? wall_clock64() : 0ull;
     SceneRef S = scene_ref(scene);
     RT_WAVE_STACK(stk, F, kTapSlots);
     __shared__ float s_grid_off[kMaxGrid];
@@ -435,6 +438,13 @@ __global__ __launch_bounds__(kBlock, render_waves(F, COUNT)) void k_render(const
     work_zero(wk);
     render_tile<F, COUNT, true>(S, a, blockIdx.x, stk, s_grid_off, rgb_tiles, rgb8_tiles, wk);
     flush_work(wk, counters, COUNT);
+    if (tile_times) {  // (kernel-uniform)
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned long long dt = wall_clock64() - t0;
+            tile_times[blockIdx.x] = dt > 0xfffffffeull ? 0xfffffffeu : (uint32_t)dt;
+        }
+    }
 }
 
 // The same frame with the taps of a pixel spread over the waves of a block.  PH = 1: block b renders the
@@ -604,7 +614,8 @@ __device__ __forceinline__ void render_tile_part(SceneRef S, const RenderArgs &a
 
 template <int F, bool COUNT, int PH>
 __global__ __launch_bounds__(kBlock, split_waves(F, COUNT)) void k_render_split(const DevScene *scene, RenderArgs a, float *rgb_tiles,
-                                                                                 uint8_t *rgb8_tiles, unsigned long long *counters) {
+                                                                                 uint8_t *rgb8_tiles, unsigned long long *counters,
+                                                                                 uint32_t * /*tile_times: k_render's argument list*/) {
     SceneRef S = scene_ref(scene);
     unbundle(a);
     RT_WAVE_STACK(stk, F, kSplitSlots);
@@ -1564,14 +1575,15 @@ static int queue_slots_of(rt_ctx *ctx) {
 }
 
 // Which kernel renders a launch.  The rule is fixed (no timing).  A block of k_render walks all taps of its pixels
-// one after the other, and a tile on a mesh takes many times as long as the average tile: with many taps per pixel,
-// or with so few tiles that the launch is only a few such blocks long (one GPU's share of a frame on a node of
-// several), the longest blocks decide the time.  There k_render_hybrid renders the tiles that took long in the
-// previous frame with four blocks each (measured on one GPU's share of the 4K teapot frame at 2 / 4 GPUs:
-// 1.27 / 0.67 ms against k_render's 1.9 / 1.3), and for launches of under four rounds of resident blocks (a share
-// at 8 GPUs) the persistent k_render_queue hands the heavy tiles' quadrants out first (0.39 ms against 0.42 and
-// k_render's 0.87; at 4 GPUs it loses, 0.74 against 0.67).  Everything else goes to k_render, which has the fewest
-// instructions per ray.  rt_render_params.kernel or RT_RENDER_VARIANT name another kernel.
+// one after the other, and a tile on a mesh takes many times as long as the average tile, so the longest blocks
+// decide when a launch ends: the whole frame on one GPU loses some 7 % to them, a rank's share of a frame (a launch
+// of a few rounds of blocks) half its time.  Scenes with meshes and four or more taps per pixel therefore go to
+// k_render_hybrid, which renders the tiles that took long in the previous frame with four blocks each (the 4K teapot
+// frame: 1.95 ms against k_render's 2.09; one GPU's share of it at 2 / 4 GPUs: 1.00 / 0.53 ms), and launches of
+// under four rounds of resident blocks (a share at 8 GPUs) to the persistent k_render_queue, which hands the heavy
+// tiles' quadrants out first (0.33 ms against 0.36).  Everything else goes to k_render, which has the fewest
+// instructions per ray; so does the first frame of a long launch, whose tiles' times it records (render_shard).
+// rt_render_params.kernel or RT_RENDER_VARIANT name another kernel.
 static int pick_variant(const rt_ctx *ctx, const rt_render_params *p, int local_tiles) {
     if (p->count_work) return 0;  // the counting instantiation is k_render's
     if (ctx->forced_variant >= 0) return ctx->forced_variant;
@@ -1581,14 +1593,14 @@ static int pick_variant(const rt_ctx *ctx, const rt_render_params *p, int local_
     if (!(ctx->features & F_MESH) || taps < 4) return 0;
     const int resident = 5 * ctx->n_cus;                      // blocks the GPU holds at a time
     if (local_tiles < 4 * resident) return kVariantQueue;     // a very short launch (a share of a frame on a node of eight): heaviest work first
-    const bool short_launch = local_tiles < 16 * resident;    // under 16 rounds of resident blocks
-    return (taps >= 32 || short_launch) ? 3 : 0;
+    return 3;  // (a long launch whose tiles' times are not known yet is rendered by k_render, which records them: render_shard)
 }
 
 // This rank's tiles of one frame into tile-major device buffers.  tm: where the tiles' times are kept (the
 // context's own memory, grown on demand when may_allocate, or the static array).
+// by_rule: the kernel was chosen by pick_variant's rule, not named by the caller.
 static int render_shard(rt_ctx *ctx, const rt_render_params *p, float *d_rgb_tiles, uint8_t *d_rgb8_tiles, TileMem &tm, bool may_allocate,
-                        int variant) {
+                        int variant, bool by_rule) {
     RenderArgs a;
     a.width = p->width; a.height = p->height; a.mode = p->mode; a.grid_m = p->grid_m; a.max_depth = p->max_depth;
     a.accel = p->accel; a.rank = p->rank; a.world_size = p->world_size;
@@ -1600,6 +1612,7 @@ static int render_shard(rt_ctx *ctx, const rt_render_params *p, float *d_rgb_til
     const int local_tiles = (a.tiles_total + p->world_size - 1) / p->world_size;
     if (local_tiles <= 0) return RT_OK;
     const bool timed_tiles = variant == 3 || variant == kVariantQueue;
+    uint32_t *record_times = nullptr;  // k_render leaves the tiles' times here (see below)
     if (timed_tiles) {
         if (local_tiles > tm.cap_tiles || (variant == kVariantQueue && !tm.items)) {
             if (!may_allocate)
@@ -1616,12 +1629,17 @@ static int render_shard(rt_ctx *ctx, const rt_render_params *p, float *d_rgb_til
         std::memcpy(&fov_bits, &p->fov, sizeof fov_bits);
         const int32_t key[10] = {p->width, p->height, p->mode, p->grid_m, p->max_depth, p->rank, p->world_size, fov_bits, ctx->features,
                                  (int32_t)ctx->scene_serial};
-        if (!tm.valid || std::memcmp(key, tm.key, sizeof key) != 0) {  // nothing known about these tiles: all count as heavy once
+        if (!tm.valid || std::memcmp(key, tm.key, sizeof key) != 0) {  // nothing known about these tiles
             std::memcpy(tm.key, key, sizeof key);
             tm.valid = true;
-            RT_HIP(hipMemsetAsync(tm.cost[tm.turn], 0xff, (size_t)local_tiles * sizeof(uint32_t), ctx->stream));
+            // A long launch (a whole frame on one GPU) goes through k_render once, which is the fastest kernel for a frame
+            // about which nothing is known, and leaves every tile's time for the frames that follow; a short one (a rank's
+            // share) counts all tiles as heavy once, which is what bounds its longest block.
+            if (by_rule && variant == 3 && local_tiles >= 16 * 5 * ctx->n_cus) record_times = tm.cost[tm.turn ^ 1];
+            else RT_HIP(hipMemsetAsync(tm.cost[tm.turn], 0xff, (size_t)local_tiles * sizeof(uint32_t), ctx->stream));
         }
     }
+    if (record_times) variant = 0;
     RT_HIP(hipEventRecord(ctx->ev0, ctx->stream));
     ctx->last_variant = variant;
     const int f = ctx->features;
@@ -1664,7 +1682,7 @@ static int render_shard(rt_ctx *ctx, const rt_render_params *p, float *d_rgb_til
         hipLaunchKernelGGL(hk, dim3(4 * local_tiles), dim3(kBlock), 0, ctx->stream, ctx->d_scene, a, d_rgb_tiles, d_rgb8_tiles, ctx->d_counters, tc);
         tm.turn ^= 1;
     } else {
-        typedef void (*render_fn)(const DevScene *, RenderArgs, float *, uint8_t *, unsigned long long *);
+        typedef void (*render_fn)(const DevScene *, RenderArgs, float *, uint8_t *, unsigned long long *, uint32_t *);
         render_fn kernel;
 #define RT_PICK(FEATURES, COUNT)                                                              \
     (variant == 0 ? (render_fn)k_render<FEATURES, COUNT>                                      \
@@ -1682,7 +1700,8 @@ static int render_shard(rt_ctx *ctx, const rt_render_params *p, float *d_rgb_til
 #undef RT_PICK
         const int blocks_per_tile = variant == 0 ? 1 : variant == 2 ? 8 : 4;
         hipLaunchKernelGGL(kernel, dim3(blocks_per_tile * local_tiles), dim3(kBlock), 0, ctx->stream, ctx->d_scene, a, d_rgb_tiles, d_rgb8_tiles,
-                           ctx->d_counters);
+                           ctx->d_counters, record_times);
+        if (record_times) tm.turn ^= 1;
     }
     RT_HIP(hipGetLastError());
     RT_HIP(hipEventRecord(ctx->ev1, ctx->stream));
@@ -1698,7 +1717,8 @@ extern "C" int rt_render_shard_device(rt_ctx *ctx, const rt_render_params *p, fl
     RT_HIP(hipSetDevice(ctx->device));
     int per_rank = 0, total = 0;
     rt_shard_tiles(p, &per_rank, &total);
-    return render_shard(ctx, p, d_rgb_tiles, d_rgb8_tiles, ctx->tiles, true, pick_variant(ctx, p, per_rank));
+    const bool by_rule = !p->count_work && ctx->forced_variant < 0 && p->kernel <= 0 && !ctx->split_forced;
+    return render_shard(ctx, p, d_rgb_tiles, d_rgb8_tiles, ctx->tiles, true, pick_variant(ctx, p, per_rank), by_rule);
 }
 
 extern "C" int rt_render_shard_device_noalloc(rt_ctx *ctx, const rt_render_params *p, float *d_rgb_tiles, uint8_t *d_rgb8_tiles) {
@@ -1713,7 +1733,7 @@ extern "C" int rt_render_shard_device_noalloc(rt_ctx *ctx, const rt_render_param
     // always the kernel that keeps tile times (they are what lives in the static array); one launch after the other per device
     std::lock_guard<std::mutex> lock(g_noalloc_mutex);
     RT_HIP(hipStreamWaitEvent(ctx->stream, g_noalloc_done[ctx->device], 0));
-    rc = render_shard(ctx, p, d_rgb_tiles, d_rgb8_tiles, g_noalloc[ctx->device], false, 3);
+    rc = render_shard(ctx, p, d_rgb_tiles, d_rgb8_tiles, g_noalloc[ctx->device], false, 3, false);
     RT_HIP(hipEventRecord(g_noalloc_done[ctx->device], ctx->stream));
     return rc;
 }

@@ -428,7 +428,7 @@ def test_every_render_kernel_writes_the_same_pixels(gpu_ctx):
     """The render kernels differ in who renders a pixel and when, never in its value: each kernel named through
     rt_render_params.kernel, over several frames (the per-tile and the queue kernel plan a frame from the tiles'
     times in the frame before), gives the bytes of the one-lane-per-pixel kernel.  The automatic choice is a fixed
-    rule: the same kernel for every frame of a sequence."""
+    rule (nothing is timed): the same kernel for every frame of this sequence."""
     ctx = gpu_ctx("teapot")
     kw = dict(fov=77.0, mode=rt.MODE_GRID, grid_m=3)
     ref, ref8 = ctx.render(333, 177, kernel=rt.KERNEL_PIXEL, **kw)
@@ -446,6 +446,22 @@ def test_every_render_kernel_writes_the_same_pixels(gpu_ctx):
     assert ctx.counters().render_variant == rt.KERNEL_PIXEL - 1
     gpu_ctx("analytic").render(96, 64, mode=rt.MODE_REF_AA9)
     assert gpu_ctx("analytic").counters().render_variant == rt.KERNEL_PIXEL - 1
+
+
+def test_first_frame_of_a_view_records_tile_times(gpu_ctx):
+    """A whole 4K frame of a mesh scene on one GPU: the rule's first frame of a view is k_render's, which leaves the
+    tiles' times; the frames after it are the per-tile kernel's; a new view starts over.  All the same bytes."""
+    ctx = gpu_ctx("teapot")
+    kw = dict(mode=rt.MODE_GRID, grid_m=2)
+    _, ref8 = ctx.render(3840, 2160, want_rgb=False, kernel=rt.KERNEL_PIXEL, **kw)
+    variants = []
+    for _ in range(3):
+        _, rgb8 = ctx.render(3840, 2160, want_rgb=False, **kw)
+        variants.append(ctx.counters().render_variant)
+        assert np.array_equal(rgb8, ref8)
+    assert variants == [rt.KERNEL_PIXEL - 1, rt.KERNEL_PER_TILE - 1, rt.KERNEL_PER_TILE - 1]
+    ctx.render(3840, 2160, want_rgb=False, fov=60.0, **kw)
+    assert ctx.counters().render_variant == rt.KERNEL_PIXEL - 1
 
 
 @pytest.mark.parametrize("seed", range(8))
