@@ -1542,8 +1542,8 @@ RT_HD void shade_object(SceneRef S, const u32x16 &g, const u32x16 &mr, const Clo
 // From the closest hits of a wave to shading contexts.  The lanes of a wave mostly hit the same object (an 8x8
 // pixel block on one wall): the wave fetches that object's record and material ONCE through scalar loads and every
 // lane resolves its hit with them -- no per-lane chain of dependent loads (object -> plane -> material ->
-// texture).  A wave whose lanes hit several objects takes the object of its first unresolved lane, resolves the
-// lanes that hit it, and repeats while lanes are left.  A lane without a hit gets a NaN point (its shadow rays miss
+// texture).  In a wave whose lanes hit several objects every lane reads the record of its own object (vector loads)
+// and the lanes go through the object kinds side by side.  A lane without a hit gets a NaN point (its shadow rays miss
 // everything); its other fields are not meaningful and nobody uses them.
 template <int F, bool COUNT, class Stack>
 RT_HD void surface_shade(SceneRef scene, const Closest &c, uint64_t hits, v3 ro, v3 rd, ShadeCtx &sc, Stack &stk, Work &wk) {
