@@ -214,6 +214,13 @@ __device__ __forceinline__ float ordered_to_float(int32_t i) { return __int_as_f
 // not hand the children on but keeps them on a stack of its own and builds the whole subtree of its job: the launch
 // after the levels a balanced tree would need, for what an unbalanced one has left (short ranges).
 constexpr int kSahStack = 64;  // pending siblings, one per level at most: kSahDepthLimit + log2(n) < 64
+// a leaf's box (24 bytes at a multiple of 8) as three 8-byte loads: a gather costs the texture addresser one lane per clock
+// whatever its width, and the first levels, one block each, are bound by exactly that
+__device__ __forceinline__ void load_leaf_box(const float *leaf_box, int q, float *box) {
+    const float2 *b2 = reinterpret_cast<const float2 *>(leaf_box) + 3 * (size_t)q;
+    float2 a = b2[0], b = b2[1], c = b2[2];
+    box[0] = a.x; box[1] = a.y; box[2] = b.x; box[3] = b.y; box[4] = c.x; box[5] = c.y;
+}
 __global__ __launch_bounds__(64 * kSahMaxWaves) void k_sah_level(const SahJob *jobs, int32_t *level_jobs, const float *leaf_box, int32_t *idx_even,
                                                                 int32_t *idx_odd, int32_t *c0, int32_t *c1, int32_t *node_parent,
                                                                 int32_t *leaf_parent, SahJob *next_jobs, int32_t *root, int finish) {
@@ -234,11 +241,22 @@ __global__ __launch_bounds__(64 * kSahMaxWaves) void k_sah_level(const SahJob *j
     const int32_t *idx_in = (job.depth & 1) ? idx_odd : idx_even;
     int32_t *idx_out = (job.depth & 1) ? idx_even : idx_odd;
     const int len = job.last - job.first + 1;
-    auto for_each_leaf = [&](auto &&body) {  // body(q, box) for the leaves of this thread
-        for (int k = job.first + tid; k <= job.last; k += nt) {
+    // body(q, box) for the leaves of this thread.  Four leaves at a time while the range lasts: their index and box loads
+    // are in flight together (a job of the first levels is one block, i.e. sixteen waves on one compute unit, walking tens of
+    // thousands of leaves through dependent index -> box gathers: the time of those levels is load latency).
+    auto for_each_leaf = [&](auto &&body) {
+        int k = job.first + tid;
+        for (; k + 3 * nt <= job.last; k += 4 * nt) {
+            int q[4];
+            float box[4][6];
+            for (int u = 0; u < 4; u++) q[u] = idx_in[k + u * nt];
+            for (int u = 0; u < 4; u++) load_leaf_box(leaf_box, q[u], box[u]);
+            for (int u = 0; u < 4; u++) body(q[u], box[u]);
+        }
+        for (; k <= job.last; k += nt) {
             int q = idx_in[k];
             float box[6];
-            for (int c = 0; c < 6; c++) box[c] = leaf_box[6 * q + c];
+            load_leaf_box(leaf_box, q, box);
             body(q, box);
         }
     };
@@ -266,10 +284,35 @@ __global__ __launch_bounds__(64 * kSahMaxWaves) void k_sah_level(const SahJob *j
         for (int i = tid; i < 3 * kSahBins; i += nt) cnt[i] = 0;
         if (tid == 0) s_best = -1;
         __syncthreads();
+        // The leaves arrive in Morton order, so the 64 leaves of a wave mostly fall into ONE bin of an axis (always so in
+        // the first levels, whose bins hold thousands of leaves): then the wave folds its boxes with lane shuffles and one
+        // lane updates the bin -- 7 LDS atomics per wave instead of 7 x 64 on one address, which is what the first levels'
+        // single blocks spent their time on.  Minimum, maximum and count do not depend on the order: the same bins.
         for_each_leaf([&](int, const float *box) {
+            const unsigned long long active = __builtin_amdgcn_ballot_w64(true);
             for (int a = 0; a < 3; a++) {
                 if (!usable[a]) continue;
                 int b = sah_bin(0.5f * (box[a] + box[3 + a]), clo[a], ext[a]);
+                const int b_first = __builtin_amdgcn_readfirstlane(b);
+                if (active == ~0ull && __builtin_amdgcn_ballot_w64(b != b_first) == 0) {  // (wave-uniform) a full wave, one bin
+                    int32_t key[6];
+                    for (int c = 0; c < 3; c++) {
+                        float lo = box[c], hi = box[3 + c];
+                        key[c] = lo == lo ? float_to_ordered(lo) : 0x7fffffff;       // (a NaN bound takes no part)
+                        key[3 + c] = hi == hi ? float_to_ordered(hi) : (int32_t)0x80000000;
+                    }
+                    for (int off = 32; off >= 1; off >>= 1)
+                        for (int c = 0; c < 3; c++) {
+                            int32_t o_lo = __shfl_xor(key[c], off), o_hi = __shfl_xor(key[3 + c], off);
+                            key[c] = o_lo < key[c] ? o_lo : key[c];
+                            key[3 + c] = o_hi > key[3 + c] ? o_hi : key[3 + c];
+                        }
+                    if (lane == 0) {
+                        for (int c = 0; c < 3; c++) { atomicMin(&s_bins[a][b_first][c], key[c]); atomicMax(&s_bins[a][b_first][3 + c], key[3 + c]); }
+                        atomicAdd(&s_cnt[a][b_first], 64);
+                    }
+                    continue;
+                }
                 for (int c = 0; c < 3; c++) {
                     float lo = box[c], hi = box[3 + c];
                     if (lo == lo) atomicMin(&s_bins[a][b][c], float_to_ordered(lo));  // fminf / fmaxf skip a NaN
@@ -327,10 +370,16 @@ __global__ __launch_bounds__(64 * kSahMaxWaves) void k_sah_level(const SahJob *j
         lbase += lsum; rbase += rsum;
         __syncthreads();
     };
-    for (int k0 = job.first; k0 <= job.last; k0 += nt) {
-        int k = k0 + tid;
-        int q = k <= job.last ? idx_in[k] : 0;
-        place(k, q, sah_centre(leaf_box, q, axis));
+    {   // (the next chunk's leaf and centre are fetched while this chunk is placed)
+        int q = job.first + tid <= job.last ? idx_in[job.first + tid] : 0;
+        float centre = sah_centre(leaf_box, q, axis);
+        for (int k0 = job.first; k0 <= job.last; k0 += nt) {
+            const int k_next = k0 + nt + tid;
+            const int q_next = k_next <= job.last ? idx_in[k_next] : 0;
+            const float centre_next = sah_centre(leaf_box, q_next, axis);
+            place(k0 + tid, q, centre);
+            q = q_next; centre = centre_next;
+        }
     }
     if (tid == 0) {
         int32_t *next_count = level_jobs + 1;
@@ -428,8 +477,18 @@ template <int F, bool COUNT>
 __global__ __launch_bounds__(kBlock, render_waves(F, COUNT)) void k_render(const DevScene *scene, RenderArgs a, float *rgb_tiles, uint8_t *rgb8_tiles,
                                                    unsigned long long *counters, uint32_t *tile_times) {
     // tile_times (may be null): the block leaves its tile's time there (100 MHz ticks), for the kernels that choose per
-    // tile by the time a tile took in the frame before
-    const unsigned long long t0 = tile_times ? wall_clock64() : 0ull;
+    // tile by the time a tile took in the frame before.  Only mesh scenes have such kernels: in the kernels of the other
+    // scenes the pointer, the clock and the branch on them cost 10 % of a frame (registers of the tap loop spilled).
+    // The pointer and the start time wait in LDS meanwhile.
+    constexpr bool kTimes = (F & F_MESH) != 0 && !COUNT;
+    __shared__ unsigned long long s_t0;
+    __shared__ uint32_t *s_times;
+    if constexpr (kTimes) {
+        if (threadIdx.x == 0) {
+            s_times = tile_times;
+            s_t0 = tile_times ? wall_clock64() : 0ull;
+        }
+    }
     SceneRef S = scene_ref(scene);
     RT_WAVE_STACK(stk, F, kTapSlots);
     __shared__ float s_grid_off[kMaxGrid];
@@ -438,11 +497,11 @@ __global__ __launch_bounds__(kBlock, render_waves(F, COUNT)) void k_render(const
     work_zero(wk);
     render_tile<F, COUNT, true>(S, a, blockIdx.x, stk, s_grid_off, rgb_tiles, rgb8_tiles, wk);
     flush_work(wk, counters, COUNT);
-    if (tile_times) {  // (kernel-uniform)
+    if constexpr (kTimes) {
         __syncthreads();
-        if (threadIdx.x == 0) {
-            unsigned long long dt = wall_clock64() - t0;
-            tile_times[blockIdx.x] = dt > 0xfffffffeull ? 0xfffffffeu : (uint32_t)dt;
+        if (threadIdx.x == 0 && s_times != nullptr) {
+            unsigned long long dt = wall_clock64() - s_t0;
+            s_times[blockIdx.x] = dt > 0xfffffffeull ? 0xfffffffeu : (uint32_t)dt;
         }
     }
 }
