@@ -451,7 +451,7 @@ RT_HD const char *obj_rec_at(SceneRef S, int32_t i, float with) {
     return (const char *)(fresh(S, with).obj_recs + i);
 }
 RT_HD const char *light_rec_at(SceneRef S, int32_t i) {
-    return (const char *)(uintptr_t)&S.light_first[0] + (size_t)i * sizeof(LightRec);
+    return (const char *)(uintptr_t)&S.light_first[0] + (uint32_t)i * (uint32_t)sizeof(LightRec);  // (an unsigned 32-bit offset: no 64-bit shift)
 }
 
 // per-thread work counters; the counting variant is a separate template instantiation
@@ -1051,14 +1051,24 @@ RT_HD float shade_rsq(float x) {
 #endif
 }
 // pow(x, y) for x in [0, 1], y >= 0 (Phong lobe, main.cpp:678)
-RT_HD float shade_pow(float x, float y) {
+// fast: no lane of the wave has an exponent above 256 (shade_pow_fast).  One decision for the wave: the library's powf is
+// some 150 instructions, and exponents above 256 do not occur in the reference's materials.
+RT_HD uint32_t shade_pow_fast(float y) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    // (one decision for the wave: the library's powf is some 150 instructions, and exponents above 256 do not occur in
-    // the reference's materials)
-    if (__builtin_amdgcn_ballot_w64(!(y <= 256.0f)) == 0) {
+    return __builtin_amdgcn_ballot_w64(!(y <= 256.0f)) == 0 ? 1u : 0u;
+#else
+    (void)y;
+    return 0u;
+#endif
+}
+RT_HD float shade_pow(float x, float y, uint32_t fast) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (fast != 0) {
         const float p = __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x));
         return y == 0.0f ? 1.0f : p;
     }
+#else
+    (void)fast;
 #endif
     return powf(x, y);
 }
@@ -1093,6 +1103,8 @@ RT_HD bool closer(float dist, int32_t idx, const Closest &best) {
 // reference's whenever the runner-up is more than 1e-5 relative behind and the 0.01 cut is not within 1e-5 relative
 // of the winner; any lane for which that cannot be said sends the whole wave through planes_exact, the reference's
 // own sequence of divisions (a ray within 1e-5 relative of an edge where two planes meet: practically never).
+// +-0 for a vector of finite components, NaN otherwise
+RT_HD float zero_or_nan(v3 v) { return __builtin_fmaf(v.x, 0.0f, __builtin_fmaf(v.y, 0.0f, v.z * 0.0f)); }
 struct PlaneCand {
     float est;       // smallest estimate so far (INFINITY: none)
     float second;    // second smallest
@@ -1207,7 +1219,8 @@ RT_HD void planes_pass(SceneRef S, const u32x16 &g0, const u32x16 &g1, int32_t n
     // With a non-finite component the reference's dot products with +-e_a are NaN and the plane is missed (the general
     // planes' own dot products say so themselves): nf is +-0 for a finite ray and NaN otherwise, and a ray with a
     // non-finite component misses every plane.
-    const float nf = (rd.x * 0.0f + rd.y * 0.0f + rd.z * 0.0f) + (ro.x * 0.0f + ro.y * 0.0f + ro.z * 0.0f);
+    // (not a value of the reference's arithmetic, only +-0 or NaN: fused, three instructions a vector)
+    const float nf = zero_or_nan(rd) + zero_or_nan(ro);
     const float e = c.est + nf;
     const bool has = e < INFINITY;
     // (an estimate so large that e * 1.00001f is infinite counts as unsure too: the exact quotient may not be finite)
@@ -1224,7 +1237,7 @@ RT_HD void find_closest(SceneRef scene, v3 ro, v3 rd, int accel, int light, floa
     SceneRef S = fresh(scene, rd.x);
     // light: >= 0 when the wave's rays are shadow rays towards that light (wave-uniform: the light loop keeps the lanes
     // of a wave in step); planes that cannot shadow it are skipped.
-    const uint32_t light_bit = (uint32_t)light < 32u ? 1u << (light & 31) : 0u;
+    const uint32_t light_bit = (uint32_t)(1ull << umin32((uint32_t)light, 63u));  // (bit `light` of 32, 0 for any other value: a minimum and a shift)
     best.distance = INFINITY;
     best.object = -1;
     best.t = 0;
@@ -1573,7 +1586,7 @@ RT_HD void surface_shade(SceneRef scene, const Closest &c, uint64_t hits, v3 ro,
 
 // one light's contribution (main.cpp:658-685); L is the normalised direction to the light, r its distance
 template <bool COUNT>
-RT_HD void shade_light(ShadeCtx &sc, v3 light_color, v3 L, float r, Work &wk) {
+RT_HD void shade_light(ShadeCtx &sc, v3 light_color, v3 L, float r, uint32_t pow_fast, Work &wk) {
     if (COUNT) wk.shade++;
     float NdotL = clamp01(dot(sc.normal, L));
     v3 term = sc.dc * NdotL;
@@ -1584,7 +1597,7 @@ RT_HD void shade_light(ShadeCtx &sc, v3 light_color, v3 L, float r, Work &wk) {
         v3 view = -sc.d_in * shade_rsq(dot(sc.d_in, sc.d_in));  // normalize(-d_in), colour only
         v3 R = reflect(-L, sc.normal);
         float VdotR = clamp01(dot(view, R));
-        term = term + sc.spec * shade_pow(VdotR, sc.shininess);
+        term = term + sc.spec * shade_pow(VdotR, sc.shininess, pow_fast);
     }
     r = (r < 0.1f) ? 0.1f : r;
     float inv_r = shade_rcp(r);
@@ -1612,6 +1625,7 @@ RT_HD void shade_lights(SceneRef scene, uint64_t hits, int accel, ShadeCtx &sc, 
     const bool hit = wave_mask_bit(hits);
     SceneRef S0 = fresh(scene, sc.point.x);
     const int32_t n_lights = S0.n_lights;
+    const uint32_t pow_fast = shade_pow_fast(sc.shininess);  // (the exponent does not change in the loop: as an integer, not a lane mask)
     for (int32_t l = 0; l < n_lights; l++) {
         const char *rec = light_rec_at(fresh(scene, sc.point.y), l);
         u32x16 lr = load_u32x16(rec), lc = load_u32x16(rec + 64);  // (both halves in one batch: the second is only looked at for a cullable light)
@@ -1642,7 +1656,9 @@ RT_HD void shade_lights(SceneRef scene, uint64_t hits, int accel, ShadeCtx &sc, 
         bool lit = hit;
         v3 L;
         float r;
-        if (traced_mask != 0) {  // (wave-uniform)
+        // (wave-uniform; marked as the rarer case: the register copies at the join of the two cases go where the compiler
+        // thinks less time is spent, and without the mark that was, after an unrelated change, the common case: 22 per light)
+        if (__builtin_expect(traced_mask != 0, 0)) {
             {
                 const float len = sqrtf(d2), inv_len = 1.0f / len;
                 v3 Le = Lv * inv_len;  // glm::normalize(light - point)
@@ -1674,7 +1690,7 @@ RT_HD void shade_lights(SceneRef scene, uint64_t hits, int accel, ShadeCtx &sc, 
             L = La;
             r = d2 * ri_approx;
         }
-        if (lit) shade_light<COUNT>(sc, light_color, L, r, wk);
+        if (lit) shade_light<COUNT>(sc, light_color, L, r, pow_fast, wk);
     }
 }
 
@@ -1833,28 +1849,26 @@ RT_HD float grid_offset(int a, int m, float s) { return ((float)a + 0.5f) / (flo
 // dx, dy: the pixel's corner X + i*s, Y - j*s (main.cpp:1244-1245; the one-tap mode adds its half pixel to the same sums, main.cpp:1263-1264)
 RT_HD float pixel_dx(const Camera &c, int i) { return c.X + i * c.s; }
 RT_HD float pixel_dy(const Camera &c, int j) { return c.Y - j * c.s; }
-RT_HD v3 primary_dir(const Camera &c, int mode, int m, float dx, float dy, int k, float &weight) {
-    float s = c.s;
-    if (mode == RT_MODE_REF_1SPP) {
-        weight = 1.0f;
-        return V3(dx + s / 2, dy + s / 2, 1);
-    }
-    if (mode == RT_MODE_REF_AA9) {
-        int kx = k % 3, ky = k / 3;
-        float tx = dx + kx * s / 2;
-        float ty = dy - ky * s / 2;
-        weight = tap_weight(mode, k);
-        return normalize(V3(tx, ty, 1));
-    }
-    int a = k % m, b = k / m;
-    float tx = dx + grid_offset(a, m, s);
-    float ty = dy - grid_offset(b, m, s);
+// The direction of tap k (main.cpp:1241-1266); GRID: tap (col, row) of the m x m taps, its offsets from a table
+// (grid_off[a] = grid_offset(a, m, s): no integer and no float division per tap), col and row advanced here.  One chain of wave-uniform cases that leave the unnormalised direction, then one normalize for the modes that
+// have one: as nested calls with a normalize each, every tap went through a dozen scalar instructions of dispatch.
+RT_HD v3 tap_dir(const Camera &c, int mode, int m, float dx, float dy, int k, int &col, int &row, const float *grid_off, float &weight) {
+    float tx, ty;
     weight = 1.0f;
+    if (mode == RT_MODE_GRID) {
+        tx = dx + grid_off[col];
+        ty = dy - grid_off[row];
+        if (++col == m) { col = 0; row++; }
+    } else if (mode == RT_MODE_REF_AA9) {
+        int kx = k % 3, ky = k / 3;
+        tx = dx + kx * c.s / 2;
+        ty = dy - ky * c.s / 2;
+        weight = tap_weight(mode, k);
+    } else {
+        return V3(dx + c.s / 2, dy + c.s / 2, 1);
+    }
     return normalize(V3(tx, ty, 1));
 }
-// The same GRID tap from a table of the m offsets (grid_off[a] = grid_offset(a, m, s)) and the tap's column
-// and row: no integer division and no float division per tap.
-RT_HD v3 primary_dir_grid(float dx, float dy, float off_x, float off_y) { return normalize(V3(dx + off_x, dy - off_y, 1)); }
 constexpr int kMaxGrid = 64;  // largest m of the GRID mode
 RT_HD void fill_grid_offsets(float *grid_off, int m, float s) {
     for (int a = 0; a < kMaxGrid; a++) grid_off[a] = a < m ? grid_offset(a, m, s) : 0.0f;
@@ -1904,13 +1918,7 @@ struct PixelTaps {
         if (k >= taps) return false;
         ro = V3(0, 0, 0);
         const float x = PARKED ? stk->cold_get(kColdTapDx) : dx, y = PARKED ? stk->cold_get(kColdTapDy) : dy;
-        if (mode == RT_MODE_GRID) {
-            rd = primary_dir_grid(x, y, grid_off[col], grid_off[row]);
-            wt = 1.0f;
-            if (++col == grid_m) { col = 0; row++; }
-        } else {
-            rd = primary_dir(cam, mode, grid_m, x, y, k, wt);
-        }
+        rd = tap_dir(cam, mode, grid_m, x, y, k, col, row, grid_off, wt);
         k++;
         return inside;
     }

@@ -539,13 +539,7 @@ struct TapSlice {  // a trace_loop source: taps [k, k_end) of one pixel; the pix
         if (k >= k_end) return false;
         ro = V3(0, 0, 0);
         const float dx = stk->cold_get(BASE), dy = stk->cold_get(BASE + 1);
-        if (mode == RT_MODE_GRID) {
-            rd = primary_dir_grid(dx, dy, grid_off[col], grid_off[row]);
-            wt = 1.0f;
-            if (++col == grid_m) { col = 0; row++; }
-        } else {
-            rd = primary_dir(cam, mode, grid_m, dx, dy, k, wt);
-        }
+        rd = tap_dir(cam, mode, grid_m, dx, dy, k, col, row, grid_off, wt);
         k++;
         return inside;
     }
