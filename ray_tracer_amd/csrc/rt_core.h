@@ -447,8 +447,12 @@ RT_HD const char *mesh_head_at(SceneRef S, int32_t i, float with) {
     return (const char *)(fresh(S, with).meshes + i);
 }
 RT_HD const char *obj_rec_at(SceneRef S, int32_t i, float with) {
-    if (i < kEmbObjects) return (const char *)(uintptr_t)&S.obj_first[i];
-    return (const char *)(fresh(S, with).obj_recs + i);
+    // (the embedded address first, from an unsigned 32-bit offset, and the table's in its place for the objects beyond:
+    // as two returns the compiler builds the case from a flag and two branches, eleven scalar instructions a sample)
+    const uint32_t off = (uint32_t)i * (uint32_t)sizeof(ObjRec);
+    const char *p = (const char *)(uintptr_t)&S.obj_first[0] + off;
+    if (i >= kEmbObjects) p = (const char *)fresh(S, with).obj_recs + off;
+    return p;
 }
 RT_HD const char *light_rec_at(SceneRef S, int32_t i) {
     return (const char *)(uintptr_t)&S.light_first[0] + (uint32_t)i * (uint32_t)sizeof(LightRec);  // (an unsigned 32-bit offset: no 64-bit shift)
@@ -815,14 +819,17 @@ RT_HD bool slab_fused(float lox, float loy, float loz, float hix, float hiy, flo
 // Branch-free form of tri_test for the traversal loop: every lane that holds a leaf runs the whole
 // test and the outcome is folded into one predicate (identical decisions, no divergent exits).
 template <bool COUNT>
-RT_HD void tri_test_flat(const f4 *tt, int32_t k, uint32_t key, v3 o, v3 d, TriBest &best, Work &wk) {
-    if (COUNT) wk.tri++;
+RT_HD void tri_test_flat(const f4 *tt, int32_t k, uint32_t key, v3 o, v3 d, bool in, TriBest &best, Work &wk) {
+    // in: the lane's ray reached this leaf.  The other lanes of the wave run the same instructions and keep what they had:
+    // a branch around the test would be the one divergent branch of the walk's loop, and with it the compiler rebuilds
+    // the whole loop's control flow from flag registers (some ten scalar instructions more per node).
+    if (COUNT) wk.tri += in ? 1u : 0u;
     f4 A = tt[3 * k], B = tt[3 * k + 1], C = tt[3 * k + 2];
     v3 p1 = V3(A.x, A.y, A.z), p2 = V3(A.w, B.x, B.y), p3 = V3(B.z, B.w, C.x), sn = V3(C.y, C.z, C.w);
     float DdotN = dot(d, sn);
     float PdotN = dot(p1 - o, sn);
     float t = PdotN / DdotN;
-    bool ok = (DdotN < 0) & (t > 0) & !((t > best.t) | ((t == best.t) & (key > best.key)));
+    bool ok = in & (DdotN < 0) & (t > 0) & !((t > best.t) | ((t == best.t) & (key > best.key)));
     v3 p = d * t + o;
     v3 sn1 = cross(p2 - p, p3 - p);
     v3 sn2 = cross(p3 - p, p1 - p);
@@ -881,7 +888,7 @@ RT_HD void bvh_walk(const BvhNode *nodes, const f4 *tt, const uint32_t *keys, in
             }
         } else {
             int32_t k = ~cur;
-            if (wave_mask_bit(inm)) tri_test_flat<COUNT>(tt, k, keys[k], o, d, best, wk);
+            tri_test_flat<COUNT>(tt, k, keys[k], o, d, wave_mask_bit(inm), best, wk);
         }
         if (sp == 0) break;
         stk.get(--sp, cur, inm);
@@ -1581,7 +1588,7 @@ RT_HD void surface_shade(SceneRef scene, const Closest &c, uint64_t hits, v3 ro,
             shade_object<F, COUNT>(S, g, mr, c, ro, rd, sc, wk);
         }
     }
-    if (!hit) sc.point = V3(NAN, NAN, NAN);
+    sc.point = select3(hit, sc.point, V3(NAN, NAN, NAN));  // (three selects: as a conditional assignment it was two branches with their mask bookkeeping)
 }
 
 // one light's contribution (main.cpp:658-685); L is the normalised direction to the light, r its distance
