@@ -1612,9 +1612,10 @@ RT_HD void shade_light(ShadeCtx &sc, v3 light_color, v3 L, float r, uint32_t pow
     sc.color = sc.color + term * (1.3f * inv_r * inv_r);
 }
 // the end of PhongModel (main.cpp:688-692)
+template <int F = F_ALL>
 RT_HD v3 shade_end(const ShadeCtx &sc) {
     v3 color = sc.color;
-    if (sc.flags & kShadeImage) color = color * unpack_rgb8(sc.occlusion_px);
+    if ((F & F_TEXTURE) && (sc.flags & kShadeImage)) color = color * unpack_rgb8(sc.occlusion_px);  // (no image textures without F_TEXTURE)
     else color = color * 4.0f;
     return color * 2.0f;
 }
@@ -1660,7 +1661,7 @@ RT_HD void shade_lights(SceneRef scene, uint64_t hits, int accel, ShadeCtx &sc, 
         }
         wk.rays_shadow += hit ? 1u : 0u;
         wk.shadow_q += wave_mask_bit(traced_mask) ? 1u : 0u;
-        bool lit = hit;
+        uint64_t lit = hits;  // the lanes the light reaches
         v3 L;
         float r;
         // (wave-uniform; marked as the rarer case: the register copies at the join of the two cases go where the compiler
@@ -1683,7 +1684,7 @@ RT_HD void shade_lights(SceneRef scene, uint64_t hits, int accel, ShadeCtx &sc, 
                 v3 Lv2 = V3(u2f(lr2[0]), u2f(lr2[1]), u2f(lr2[2])) - sc.point;
                 const float len2 = len;  // (the length and its reciprocal are the two values held through the query)
                 const bool mine = wave_mask_bit(traced_mask);
-                lit = hit & !(mine & (cs.distance < len2));
+                lit = hits & ~(traced_mask & wave_ballot(cs.distance < len2));
                 L = Lv2 * inv_len;
                 r = len2;
                 if ((lr2[3] & kLightCullable) != 0) {  // the lanes whose ray was not traced: the 1-ulp forms, as in a wave that traces nothing
@@ -1697,7 +1698,7 @@ RT_HD void shade_lights(SceneRef scene, uint64_t hits, int accel, ShadeCtx &sc, 
             L = La;
             r = d2 * ri_approx;
         }
-        if (lit) shade_light<COUNT>(sc, light_color, L, r, pow_fast, wk);
+        if (wave_mask_bit(lit)) shade_light<COUNT>(sc, light_color, L, r, pow_fast, wk);
     }
 }
 
@@ -1739,7 +1740,7 @@ RT_HD void trace_loop_direct(SceneRef S, int accel, Stack &stk, Work &wk, Source
         surface_shade<F, COUNT>(S, c, hits, o, d, sc, stk, wk);
         shade_lights<F, COUNT>(S, hits, accel, sc, stk, wk);
         v3 radiance = V3(0, 0, 0);
-        if (wave_mask_bit(hits)) radiance = radiance + shade_end(sc) * 1.0f;
+        if (wave_mask_bit(hits)) radiance = shade_end<F>(sc);
         if (live) src.done(radiance);
     }
 }
@@ -1774,7 +1775,7 @@ RT_HD void trace_loop(SceneRef S, int max_depth, int accel, Stack &stk, Work &wk
         surface_shade<F, COUNT>(S, c, hits, o, d, sc, stk, wk);
         shade_lights<F, COUNT>(S, hits, accel, sc, stk, wk);
         if (hit) {
-            v3 local = shade_end(sc);
+            v3 local = shade_end<F>(sc);
             float refl = sc.refl, refr = sc.refr;
             float ratio = sc.ratio;
             const bool from_outside = (sc.flags & kShadeOutside) != 0;
