@@ -153,9 +153,8 @@ typedef struct {
     int32_t kernel;     /* RT_KERNEL_*: which render kernel; they all write the same pixels */
 } rt_render_params;
 
-/* RT_KERNEL_AUTO picks by a fixed rule (scenes with meshes and 4 or more taps per pixel: PER_TILE, QUEUE when
- * the launch has very few tiles, e.g. one GPU's share of a frame on a node of eight, and PIXEL for the first
- * frame of a view on one GPU, which records the tiles' times; else PIXEL).
+/* RT_KERNEL_AUTO picks by a fixed rule (scenes with meshes and 4 or more taps per pixel: QUEUE, and PIXEL for
+ * the first frame of a view on one GPU, which records the tiles' times; else PIXEL).
  * PIXEL: one lane per pixel, a block per tile.  SPLIT / SPLIT2: a pixel's taps spread over the waves of a
  * block (a quadrant / half a quadrant per block).  PER_TILE: PIXEL or SPLIT per tile, by the tile's time in
  * the previous frame.  QUEUE: persistent blocks taking tiles and quadrants from a work list, longest first. */

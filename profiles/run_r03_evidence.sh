@@ -12,9 +12,9 @@ bash profiles/run_kernel_trace.sh $tag || exit 1
 cp $(find gpurun_out/prof_$tag -name '*kernel_stats.csv' | head -1) $out/kernel_stats.csv || exit 1
 bash profiles/run_pmc.sh $tag || exit 1
 mkdir -p profiles/$tag
-python3 profiles/summarise_pmc.py gpurun_out/pmc_$tag "k_render_hybrid<1>" > profiles/$tag/pmc_teapot.json || exit 1
-python3 profiles/make_traffic.py profiles/$tag/pmc_teapot.json teapot_4k_16spp k_render_hybrid > /dev/null || exit 1
-for spec in analytic_4k_aa9:1:analytic:k_render shells_4k_64spp:2:shells_half:k_render_hybrid textured_8k_256spp:4:textured_quarter:k_render; do
+python3 profiles/summarise_pmc.py gpurun_out/pmc_$tag "k_render_queue<1>" > profiles/$tag/pmc_teapot.json || exit 1
+python3 profiles/make_traffic.py profiles/$tag/pmc_teapot.json teapot_4k_16spp k_render_queue > /dev/null || exit 1
+for spec in analytic_4k_aa9:1:analytic:k_render shells_4k_64spp:2:shells_half:k_render_queue textured_8k_256spp:4:textured_quarter:k_render; do
     IFS=: read wl div name kernel <<< "$spec"
     bash profiles/run_pmc_workload.sh ${tag}_$name $wl $div || exit 1
     python3 profiles/summarise_pmc.py gpurun_out/pmc_${tag}_$name "k_render" > profiles/$tag/pmc_$name.json || exit 1

@@ -764,23 +764,28 @@ __global__ __launch_bounds__(kPlanThreads) void k_tile_threshold(QueueHeader *q,
 // filled by the render kernel.  slots: blocks of the render launch.
 __global__ __launch_bounds__(kPlanThreads) void k_plan_tiles(QueueHeader *q, const uint32_t *cost_in, uint32_t *cost_out, uint32_t *items,
                                                              int n_tiles, int slots, uint32_t forced_threshold, int use_forced) {
-    __shared__ unsigned long long s_sum[kPlanThreads / 64];
+    __shared__ unsigned long long s_sum[kPlanThreads / 64], s_known[kPlanThreads / 64];
     __shared__ uint32_t s_scan[kPlanThreads];
     __shared__ uint32_t s_bucket[kCostBuckets], s_bucket_base[kCostBuckets];
     __shared__ uint32_t s_threshold, s_heavy;
     const int t = threadIdx.x;
-    // the threshold: a sixteenth of the launch's expected length (sum of the known times / slots), so that whatever
-    // is handed out last is short against the whole; tiles of unknown time do not enter the sum
-    unsigned long long sum = 0;
-    for (int i = t; i < n_tiles; i += kPlanThreads) { uint32_t c = cost_in[i]; if (c != 0xffffffffu) sum += c; }
-    sum = wave_sum(sum);
-    if ((t & 63) == 0) s_sum[t >> 6] = sum;
+    // The threshold: a sixteenth of the launch's expected length (sum of the known times / slots), so that whatever is
+    // handed out last is short against the whole, but not under the mean tile: a quadrant item costs more per pixel than
+    // a whole tile, and a list of nothing but quadrants is a quarter slower than one that splits the tiles above the
+    // mean (measured on one rank's share of the 4K teapot frame at 1 / 2 / 4 / 8 ranks: 1.73 / 0.87 / 0.46 / 0.26 ms
+    // with this rule, 1.76 / 0.90 / 0.57 / 0.31 with the sixteenth alone).  Tiles of unknown time do not enter the sums.
+    unsigned long long sum = 0, known = 0;
+    for (int i = t; i < n_tiles; i += kPlanThreads) { uint32_t c = cost_in[i]; if (c != 0xffffffffu) { sum += c; known++; } }
+    sum = wave_sum(sum); known = wave_sum(known);
+    if ((t & 63) == 0) { s_sum[t >> 6] = sum; s_known[t >> 6] = known; }
     if (t < kCostBuckets) s_bucket[t] = 0;
     __syncthreads();
     if (t == 0) {
-        unsigned long long total = 0;
-        for (int w = 0; w < kPlanThreads / 64; w++) total += s_sum[w];
+        unsigned long long total = 0, n_known = 0;
+        for (int w = 0; w < kPlanThreads / 64; w++) { total += s_sum[w]; n_known += s_known[w]; }
         unsigned long long th = total / (unsigned long long)(slots > 0 ? slots : 1) / 16ull;
+        const unsigned long long mean = total / (n_known > 0 ? n_known : 1ull);
+        if (th < mean) th = mean;
         s_threshold = use_forced ? forced_threshold : (th > 0xfffffffeull ? 0xfffffffeu : (uint32_t)th);
         s_heavy = 0;
     }
@@ -1629,13 +1634,13 @@ static int queue_slots_of(rt_ctx *ctx) {
 
 // Which kernel renders a launch.  The rule is fixed (no timing).  A block of k_render walks all taps of its pixels
 // one after the other, and a tile on a mesh takes many times as long as the average tile, so the longest blocks
-// decide when a launch ends: the whole frame on one GPU loses some 7 % to them, a rank's share of a frame (a launch
-// of a few rounds of blocks) half its time.  Scenes with meshes and four or more taps per pixel therefore go to
-// k_render_hybrid, which renders the tiles that took long in the previous frame with four blocks each (the 4K teapot
-// frame: 1.95 ms against k_render's 2.09; one GPU's share of it at 2 / 4 GPUs: 1.00 / 0.53 ms), and launches of
-// under four rounds of resident blocks (a share at 8 GPUs) to the persistent k_render_queue, which hands the heavy
-// tiles' quadrants out first (0.33 ms against 0.36).  Everything else goes to k_render, which has the fewest
-// instructions per ray; so does the first frame of a long launch, whose tiles' times it records (render_shard).
+// decide when a launch ends: the whole frame on one GPU loses a tenth to them, a rank's share of a frame (a launch
+// of a few rounds of blocks) half its time.  Scenes with meshes and four or more taps per pixel therefore go to the
+// persistent k_render_queue, which hands out the quadrants of the tiles that took long in the previous frame first and
+// the other tiles whole after them (the 4K teapot frame: 1.69 ms against k_render's 1.93; one GPU's share of it at
+// 2 / 4 / 8 GPUs: 0.87 / 0.46 / 0.26 ms).  k_render_hybrid, which decides per tile without a list, is 2 to 20 % behind it
+// at these sizes and stays selectable by name.  Everything else goes to k_render, which has the fewest instructions per
+// ray; so does the first frame of a long launch, whose tiles' times it records (render_shard).
 // rt_render_params.kernel or RT_RENDER_VARIANT name another kernel.
 static int pick_variant(const rt_ctx *ctx, const rt_render_params *p, int local_tiles) {
     if (p->count_work) return 0;  // the counting instantiation is k_render's
@@ -1644,9 +1649,8 @@ static int pick_variant(const rt_ctx *ctx, const rt_render_params *p, int local_
     const int taps = taps_of(p->mode, p->grid_m);
     if (ctx->split_forced) return taps >= ctx->split_min_taps ? ctx->split_phases : 0;
     if (!(ctx->features & F_MESH) || taps < 4) return 0;
-    const int resident = 5 * ctx->n_cus;                      // blocks the GPU holds at a time
-    if (local_tiles < 4 * resident) return kVariantQueue;     // a very short launch (a share of a frame on a node of eight): heaviest work first
-    return 3;  // (a long launch whose tiles' times are not known yet is rendered by k_render, which records them: render_shard)
+    (void)local_tiles;
+    return kVariantQueue;  // (a long launch whose tiles' times are not known yet is rendered by k_render, which records them: render_shard)
 }
 
 // This rank's tiles of one frame into tile-major device buffers.  tm: where the tiles' times are kept (the
@@ -1688,7 +1692,7 @@ static int render_shard(rt_ctx *ctx, const rt_render_params *p, float *d_rgb_til
             // A long launch (a whole frame on one GPU) goes through k_render once, which is the fastest kernel for a frame
             // about which nothing is known, and leaves every tile's time for the frames that follow; a short one (a rank's
             // share) counts all tiles as heavy once, which is what bounds its longest block.
-            if (by_rule && variant == 3 && local_tiles >= 16 * 5 * ctx->n_cus) record_times = tm.cost[tm.turn ^ 1];
+            if (by_rule && local_tiles >= 16 * 5 * ctx->n_cus) record_times = tm.cost[tm.turn ^ 1];
             else RT_HIP(hipMemsetAsync(tm.cost[tm.turn], 0xff, (size_t)local_tiles * sizeof(uint32_t), ctx->stream));
         }
     }

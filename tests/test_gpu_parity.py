@@ -439,7 +439,7 @@ def test_every_render_kernel_writes_the_same_pixels(gpu_ctx):
             rgb, rgb8 = ctx.render(333, 177, kernel=kernel, **kw)
             variants.append(ctx.counters().render_variant)
             assert np.array_equal(rgb8, ref8) and np.array_equal(rgb, ref, equal_nan=True), (kernel, variants)
-        expect = kernel - 1 if kernel != rt.KERNEL_AUTO else rt.KERNEL_QUEUE - 1  # a mesh scene, nine taps, a very short launch
+        expect = kernel - 1 if kernel != rt.KERNEL_AUTO else rt.KERNEL_QUEUE - 1  # a mesh scene, nine taps, the queue kernel
         assert variants == [expect] * 4
     # scenes without meshes, and single-tap frames, go to the one-lane-per-pixel kernel
     ctx.render(96, 64, mode=rt.MODE_REF_1SPP)
@@ -450,7 +450,7 @@ def test_every_render_kernel_writes_the_same_pixels(gpu_ctx):
 
 def test_first_frame_of_a_view_records_tile_times(gpu_ctx):
     """A whole 4K frame of a mesh scene on one GPU: the rule's first frame of a view is k_render's, which leaves the
-    tiles' times; the frames after it are the per-tile kernel's; a new view starts over.  All the same bytes."""
+    tiles' times; the frames after it are the queue kernel's; a new view starts over.  All the same bytes."""
     ctx = gpu_ctx("teapot")
     kw = dict(mode=rt.MODE_GRID, grid_m=2)
     _, ref8 = ctx.render(3840, 2160, want_rgb=False, kernel=rt.KERNEL_PIXEL, **kw)
@@ -459,7 +459,7 @@ def test_first_frame_of_a_view_records_tile_times(gpu_ctx):
         _, rgb8 = ctx.render(3840, 2160, want_rgb=False, **kw)
         variants.append(ctx.counters().render_variant)
         assert np.array_equal(rgb8, ref8)
-    assert variants == [rt.KERNEL_PIXEL - 1, rt.KERNEL_PER_TILE - 1, rt.KERNEL_PER_TILE - 1]
+    assert variants == [rt.KERNEL_PIXEL - 1, rt.KERNEL_QUEUE - 1, rt.KERNEL_QUEUE - 1]
     ctx.render(3840, 2160, want_rgb=False, fov=60.0, **kw)
     assert ctx.counters().render_variant == rt.KERNEL_PIXEL - 1
 
