@@ -760,41 +760,87 @@ __global__ __launch_bounds__(kPlanThreads) void k_tile_threshold(QueueHeader *q,
     }
 }
 
+// The lanes of a wave with `on` add one each to s_bucket[b] (b: the lane's bucket), one atomic per distinct bucket among
+// them; returns the lane's index within its bucket.  Called by whole waves.
+__device__ __forceinline__ uint32_t bucket_take(uint32_t *s_bucket, bool on, int b) {
+    const int lane = threadIdx.x & 63;
+    uint32_t pos = 0;
+    uint64_t todo = __builtin_amdgcn_ballot_w64(on);
+    while (todo != 0) {  // (wave-uniform)
+        const int leader = __builtin_ctzll(todo);
+        const int lb = __builtin_amdgcn_readlane(b, leader);
+        const bool mine = on && b == lb;
+        const uint64_t same = __builtin_amdgcn_ballot_w64(mine);
+        uint32_t first = 0;
+        if (lane == leader) first = atomicAdd(&s_bucket[lb], (uint32_t)__builtin_popcountll(same));
+        first = (uint32_t)__builtin_amdgcn_readlane((int)first, leader);
+        if (mine) pos = first + (uint32_t)__builtin_popcountll(same & ((1ull << lane) - 1ull));
+        todo &= ~same;
+    }
+    return pos;
+}
+
 // One block.  cost_in: last frame's time per tile (0xffffffff: unknown, counts as heavy); cost_out: zeroed here,
 // filled by the render kernel.  slots: blocks of the render launch.
-__global__ __launch_bounds__(kPlanThreads) void k_plan_tiles(QueueHeader *q, const uint32_t *cost_in, uint32_t *cost_out, uint32_t *items,
-                                                             int n_tiles, int slots, uint32_t forced_threshold, int use_forced) {
-    __shared__ unsigned long long s_sum[kPlanThreads / 64], s_known[kPlanThreads / 64];
-    __shared__ uint32_t s_scan[kPlanThreads];
+// Every pass takes the tiles in batches of kPlanBatch: a thread fetches its kPlanPerThread times of a batch with loads
+// that are all in flight together and works on them from registers (one block alone has too few waves to hide a
+// memory round trip per step: with a load in every step of every pass this kernel took 72 us for a 4K frame).
+constexpr int kPlanPerThread = 32, kPlanBatch = kPlanPerThread * kPlanThreads, kPlanWaves = kPlanThreads / 64;
+__device__ __forceinline__ void plan_fetch(const uint32_t *__restrict__ cost_in, int first, int n_tiles, uint32_t (&c)[kPlanPerThread]) {
+#pragma unroll
+    for (int k = 0; k < kPlanPerThread; k++) {
+        const int i = first + k * kPlanThreads + (int)threadIdx.x;
+        c[k] = i < n_tiles ? cost_in[i] : 0u;  // (0: neither heavy nor, as an index out of range, light)
+    }
+}
+__global__ __launch_bounds__(kPlanThreads) void k_plan_tiles(QueueHeader *q, const uint32_t *__restrict__ cost_in, uint32_t *__restrict__ cost_out,
+                                                             uint32_t *__restrict__ items, int n_tiles, int slots, uint32_t forced_threshold,
+                                                             int use_forced) {
+    __shared__ unsigned long long s_sum[kPlanWaves], s_known[kPlanWaves];
+    __shared__ uint32_t s_light[kPlanPerThread * kPlanWaves];  // light tiles of a batch by (step, wave), then their running sum
     __shared__ uint32_t s_bucket[kCostBuckets], s_bucket_base[kCostBuckets];
-    __shared__ uint32_t s_threshold, s_heavy;
-    const int t = threadIdx.x;
+    __shared__ uint32_t s_threshold, s_heavy, s_light_before;
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    uint32_t c[kPlanPerThread];
     // The threshold: a sixteenth of the launch's expected length (sum of the known times / slots), so that whatever is
     // handed out last is short against the whole, but not under the mean tile: a quadrant item costs more per pixel than
     // a whole tile, and a list of nothing but quadrants is a quarter slower than one that splits the tiles above the
     // mean (measured on one rank's share of the 4K teapot frame at 1 / 2 / 4 / 8 ranks: 1.73 / 0.87 / 0.46 / 0.26 ms
     // with this rule, 1.76 / 0.90 / 0.57 / 0.31 with the sixteenth alone).  Tiles of unknown time do not enter the sums.
     unsigned long long sum = 0, known = 0;
-    for (int i = t; i < n_tiles; i += kPlanThreads) { uint32_t c = cost_in[i]; if (c != 0xffffffffu) { sum += c; known++; } }
+    for (int first = 0; first < n_tiles; first += kPlanBatch) {
+        plan_fetch(cost_in, first, n_tiles, c);
+#pragma unroll
+        for (int k = 0; k < kPlanPerThread; k++) {
+            const bool is_known = first + k * kPlanThreads + t < n_tiles && c[k] != 0xffffffffu;
+            sum += is_known ? c[k] : 0u; known += is_known ? 1u : 0u;
+        }
+    }
     sum = wave_sum(sum); known = wave_sum(known);
-    if ((t & 63) == 0) { s_sum[t >> 6] = sum; s_known[t >> 6] = known; }
+    if (lane == 0) { s_sum[wave] = sum; s_known[wave] = known; }
     if (t < kCostBuckets) s_bucket[t] = 0;
     __syncthreads();
     if (t == 0) {
         unsigned long long total = 0, n_known = 0;
-        for (int w = 0; w < kPlanThreads / 64; w++) { total += s_sum[w]; n_known += s_known[w]; }
+        for (int w = 0; w < kPlanWaves; w++) { total += s_sum[w]; n_known += s_known[w]; }
         unsigned long long th = total / (unsigned long long)(slots > 0 ? slots : 1) / 16ull;
         const unsigned long long mean = total / (n_known > 0 ? n_known : 1ull);
         if (th < mean) th = mean;
         s_threshold = use_forced ? forced_threshold : (th > 0xfffffffeull ? 0xfffffffeu : (uint32_t)th);
-        s_heavy = 0;
+        s_heavy = 0; s_light_before = 0;
     }
     __syncthreads();
     const uint32_t threshold = s_threshold;
-    // heavy tiles by bucket of floor(log2(time)), longest first; within a bucket in order of arrival
-    for (int i = t; i < n_tiles; i += kPlanThreads) {
-        uint32_t c = cost_in[i];
-        if (c > threshold) atomicAdd(&s_bucket[31 - __clz(c | 1u)], 1u);
+    // heavy tiles by bucket of floor(log2(time)), longest first; within a bucket in order of arrival.  (The lanes of a
+    // wave add to a bucket together, bucket_take: a frame's heavy tiles fall into two or three buckets, and one atomic
+    // per lane on so few addresses is a queue of sixty-four.)
+    for (int first = 0; first < n_tiles; first += kPlanBatch) {
+        plan_fetch(cost_in, first, n_tiles, c);
+#pragma unroll
+        for (int k = 0; k < kPlanPerThread; k++) {
+            if (first + k * kPlanThreads >= n_tiles) break;  // (block-uniform)
+            bucket_take(s_bucket, c[k] > threshold, 31 - __clz(c[k] | 1u));
+        }
     }
     __syncthreads();
     if (t == 0) {
@@ -804,30 +850,48 @@ __global__ __launch_bounds__(kPlanThreads) void k_plan_tiles(QueueHeader *q, con
     }
     __syncthreads();
     const uint32_t n_heavy = s_heavy;
-    for (int i = t; i < n_tiles; i += kPlanThreads) {
-        uint32_t c = cost_in[i];
-        if (c > threshold) {
-            int b = 31 - __clz(c | 1u);
-            uint32_t pos = s_bucket_base[b] + atomicAdd(&s_bucket[b], 1u);
-            for (uint32_t quad = 0; quad < 4; quad++) items[4 * pos + quad] = (uint32_t)i | (quad << 28) | kItemQuadrant;
+    // The heavy tiles' quadrants into their buckets; the light tiles behind all of them in frame order: step k of a batch
+    // gives wave w tiles first + k * kPlanThreads + 64 w .. + 63, so the (step, wave) pairs in order are the frame order,
+    // and a running sum over their counts of light tiles says where each pair's tiles go.
+    for (int first = 0; first < n_tiles; first += kPlanBatch) {
+        plan_fetch(cost_in, first, n_tiles, c);
+#pragma unroll
+        for (int k = 0; k < kPlanPerThread; k++) {
+            const int i = first + k * kPlanThreads + t;
+            const bool heavy = c[k] > threshold;
+            uint64_t lights = 0;
+            if (first + k * kPlanThreads < n_tiles) {  // (block-uniform)
+                const int b = 31 - __clz(c[k] | 1u);
+                const uint32_t pos = s_bucket_base[b] + bucket_take(s_bucket, heavy, b);
+                if (heavy)
+                    for (uint32_t quad = 0; quad < 4; quad++) items[4 * pos + quad] = (uint32_t)i | (quad << 28) | kItemQuadrant;
+                lights = __builtin_amdgcn_ballot_w64(i < n_tiles && !heavy);
+            }
+            if (lane == 0) s_light[k * kPlanWaves + wave] = (uint32_t)__builtin_popcountll(lights);
         }
-    }
-    // light tiles after them, in frame order: every thread owns a run of consecutive tiles
-    const int run = (n_tiles + kPlanThreads - 1) / kPlanThreads;
-    const int lo = t * run, hi = lo + run < n_tiles ? lo + run : n_tiles;
-    uint32_t mine = 0;
-    for (int i = lo; i < hi; i++) mine += cost_in[i] > threshold ? 0u : 1u;
-    s_scan[t] = mine;
-    __syncthreads();
-    for (int off = 1; off < kPlanThreads; off <<= 1) {
-        uint32_t v = t >= off ? s_scan[t - off] : 0u;
         __syncthreads();
-        s_scan[t] += v;
+        if (wave == 0) {  // the running sum, by one wave: a lane adds up its eight consecutive counts, the lanes' sums are scanned
+            constexpr int kPer = kPlanPerThread * kPlanWaves / 64;
+            uint32_t v[kPer], mine = 0;
+#pragma unroll
+            for (int j = 0; j < kPer; j++) { v[j] = s_light[lane * kPer + j]; mine += v[j]; }
+            uint32_t incl = mine;
+            for (int off = 1; off < 64; off <<= 1) { uint32_t o = __shfl_up(incl, off, 64); if (lane >= off) incl += o; }
+            uint32_t run = s_light_before + incl - mine;
+#pragma unroll
+            for (int j = 0; j < kPer; j++) { s_light[lane * kPer + j] = run; run += v[j]; }
+            if (lane == 63) s_light_before = run;  // (read by every lane above, before this store: one wave, in step)
+        }
         __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kPlanPerThread; k++) {
+            const int i = first + k * kPlanThreads + t;
+            const bool light = i < n_tiles && !(c[k] > threshold);
+            const uint64_t m = __builtin_amdgcn_ballot_w64(light);
+            if (light) items[4 * n_heavy + s_light[k * kPlanWaves + wave] + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = (uint32_t)i;
+        }
+        __syncthreads();  // (s_light is rewritten by the next batch)
     }
-    uint32_t at = 4 * n_heavy + s_scan[t] - mine;
-    for (int i = lo; i < hi; i++)
-        if (!(cost_in[i] > threshold)) items[at++] = (uint32_t)i;
     for (int i = t; i < n_tiles; i += kPlanThreads) cost_out[i] = 0;
     if (t == 0) { q->next = 0; q->n_items = 3 * n_heavy + (uint32_t)n_tiles; q->n_heavy = n_heavy; q->threshold = threshold; }
 }
