@@ -6,7 +6,7 @@ function whose body holds the line its `.loc` directive names (the innermost inl
 compiler's resource usage for the kernel and, per source function, the instruction counts by class
 (VALU / SALU / branch / scalar memory / LDS / vector memory / waits and nops).  The counts are static (one per
 instruction in the binary, however often it runs); together with how often a phase runs per sample they give
-the per-phase budget in DESIGN.md.
+a per-phase instruction budget.
 
 usage: python profiles/isa_report.py [--lean] [--keep /tmp/x.s] [--flags "..."] k_renderILi1ELb0
 """
