@@ -448,6 +448,18 @@ def test_every_render_kernel_writes_the_same_pixels(gpu_ctx):
     assert gpu_ctx("analytic").counters().render_variant == rt.KERNEL_PIXEL - 1
 
 
+def test_queue_kernel_list_of_more_tiles_than_one_planning_batch(gpu_ctx):
+    """A frame of 82 944 tiles: the planning kernel takes the tiles in batches of 32 768, and the list it leaves must hold
+    every tile once, the second time round from recorded times (some tiles split).  Same bytes as the pixel kernel."""
+    ctx = gpu_ctx("teapot")
+    kw = dict(mode=rt.MODE_GRID, grid_m=2, want_rgb=False)
+    _, ref8 = ctx.render(4608, 4608, kernel=rt.KERNEL_PIXEL, **kw)
+    for _ in range(3):
+        _, rgb8 = ctx.render(4608, 4608, kernel=rt.KERNEL_QUEUE, **kw)
+        assert ctx.counters().render_variant == rt.KERNEL_QUEUE - 1
+        assert np.array_equal(rgb8, ref8)
+
+
 def test_first_frame_of_a_view_records_tile_times(gpu_ctx):
     """A whole 4K frame of a mesh scene on one GPU: the rule's first frame of a view is k_render's, which leaves the
     tiles' times; the frames after it are the queue kernel's; a new view starts over.  All the same bytes."""
